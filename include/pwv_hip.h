@@ -1,0 +1,185 @@
+/*
+ * pwv_hip.h -- C ABI of libpwv_hip.so: the MI355X (gfx950) kernels of the IAF-WaveNet
+ * student generation path of andabi/parallel-wavenet-vocoder.
+ *
+ * The reference has NO FFI / plugin interface for this path: it is Python calling stock
+ * TensorFlow ops.  Each entry point below therefore cites the
+ * reference *Python call site* (file:line in /root/reference) whose arithmetic it replaces.
+ * The Python host (parallel-wavenet-vocoder_amd/{modules,models}.py) binds them with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (never retained or freed here),
+ *     float32, channels-last [N, T, C]; TensorFlow weight layout [width, Cin, Cout];
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
+ *     (no hidden synchronisation, no internal streams or threads; re-entrant per stream);
+ *   - return 0 on success, a negative PWV_E* code otherwise; pwv_last_error() returns a
+ *     thread-local message for the last failing call on this thread;
+ *   - "packed" buffers hold weights re-laid-out for the MFMA A-operand; their size comes
+ *     from the matching pwv_*_packed_floats() call and their content from pwv_pack_*().
+ */
+#ifndef PWV_HIP_H_
+#define PWV_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWV_OK 0
+#define PWV_EINVAL (-1)      /* bad argument / unsupported shape */
+#define PWV_EHIP (-2)        /* HIP runtime error (message in pwv_last_error) */
+
+#define PWV_MAX_NETS 2       /* nets evaluated side by side in one launch (scalar, shifter) */
+
+/* arithmetic of the fused layer / head kernels */
+#define PWV_PREC_F32 0       /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains */
+#define PWV_PREC_F16X3 1     /* 3-term split-fp16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+
+typedef void* pwv_stream_t;
+
+const char* pwv_last_error(void);
+int pwv_version(void);
+/* number of compute units of the current device (grid sizing); <0 on error */
+int pwv_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------
+ * modules.causal_conv(value, filter_, dilation)                      modules.py:11-43
+ *   y[n,t,:] = sum_k x[n, t-(W-1-k)*d, :] @ f[k],  x[t<0] = 0,  len(y) == len(x)
+ *   x [N,T,Cin], f [W,Cin,Cout], y [N,T,Cout].  Any W, Cin, Cout, dilation >= 1.
+ * ------------------------------------------------------------------------------------- */
+int pwv_causal_conv_f32(const float* x, const float* filt, float* y,
+                        int N, int T, int Cin, int Cout, int W, int dilation,
+                        pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * y[M,Nout] = act(x[M,K] @ w[K,Nout] + bias)   (bias may be NULL; relu: 0/1)
+ * The 1x1 convolutions of the path that are plain GEMMs: cond `dense` (models.py:128-130),
+ * each conv2d_transpose stage, whose kernel width == stride makes it a per-frame GEMM
+ * (models.py:110-120), and the frame-rate projection of the condition through every layer's
+ * gc_filter / gc_gate (+ filter_bias / gate_bias) (modules.py:216-228, hoisted).
+ * K % 8 == 0, K <= 128, Nout % 4 == 0.
+ * ------------------------------------------------------------------------------------- */
+int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y,
+                   int M, int K, int Nout, int relu, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * IAFVocoder._upsample_cond, 'repeat' branch: tile + reshape + crop   models.py:131-133
+ *   out[n, t, :] = frames[n, (t + offset) / hop, :],  t in [0, T)
+ *   frames [N, t_mel, C] (already relu(mel @ dense)), out [N, T, C].
+ * ------------------------------------------------------------------------------------- */
+int pwv_upsample_repeat_f32(const float* frames, float* out, int N, int t_mel, int C,
+                            int T, int hop, int offset, pwv_stream_t stream);
+
+/* out[n, t, :] = in[n, t + offset, :]  (the crop at models.py:124) */
+int pwv_crop_time_f32(const float* in, float* out, int N, int T_in, int C, int T_out, int offset,
+                      pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Logistic(0,1).sample                                               models.py:32-33
+ *   z = log(u) - log1p(-u),  u ~ U(0,1) from a counter-based generator keyed by
+ *   (seed, element index + offset): reproducible and shardable.
+ * ------------------------------------------------------------------------------------- */
+int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LinearIAFLayer affine + the next flow's causal layer, fused.
+ *   x[r] = z[r]*s[r*sb_stride] + b[r*sb_stride]          modules.py:59   (x = z if s == NULL)
+ *   h_g[n,t,:] = sum_k x[n, t-(W-1-k), 0] * filt_g[k,0,:]  modules.py:179-180 (no bias)
+ * z [N*T]; s, b strided views of the previous flow's net outputs; x_out [N*T] (may be NULL
+ * when s == NULL); for g < G: filt[g] is [W,1,R], h[g] is [N,T,R].  G may be 0 (affine only).
+ * ------------------------------------------------------------------------------------- */
+int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_stride,
+                      float* x_out, int G, const float* const* filt, float* const* h,
+                      int N, int T, int W, int R, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused gated-residual layer: WaveNet._create_dilation_layer          modules.py:185-259
+ * for R = D = 64, S = 128, filter_width 2 (hparams/default.yaml:22-25), G <= 2 nets per launch.
+ *
+ *   F‖G = [x[t-d] ‖ x[t]] @ [[filter0‖gate0],[filter1‖gate1]] + P[frame(t)]   (+ cond[t] @ gc)
+ *   o   = tanh(F) * sigmoid(G)                                                  modules.py:236
+ *   out = x[t] + o @ dense + dense_bias        (out_mode PWV_OUT_RESIDUAL)     modules.py:239-251
+ *   out = o                                    (out_mode PWV_OUT_GATED: last layer -> head)
+ *   skip (+)= o @ skip_w + skip_bias           (when skip != NULL)              modules.py:243-250
+ *
+ * P is the frame-rate projection of the condition through gc_filter‖gc_gate plus
+ * filter_bias‖gate_bias, in the kernel's column order (pwv_proj_column_map); the row used by
+ * sample t of utterance n is  n*cond_frames + (t + cond_offset)/cond_hop  (cond_hop == 0:
+ * always row 0, i.e. biases only / no conditioning).  `cond` (per-sample condition
+ * [N,T,80], transposed-conv upsampling) is NULL in hoisted mode.
+ * ------------------------------------------------------------------------------------- */
+#define PWV_OUT_RESIDUAL 0
+#define PWV_OUT_GATED 1
+
+/* floats of one layer's packed buffer; with_skip / with_cond select optional sections */
+size_t pwv_layer_packed_floats(int with_skip, int cond_channels);
+
+/* gather TF-layout weights (device) into the packed layout (device).
+ * filter, gate [2,64,64]; dense [1,64,64]; dense_bias [64] or NULL;
+ * skip [1,64,128] + skip_bias [128]/NULL when with_skip; gc_filter, gc_gate [1,C,64] when
+ * cond_channels > 0 (per-sample conditioning). */
+int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dense,
+                       const float* dense_bias, const float* skip, const float* skip_bias,
+                       const float* gc_filter, const float* gc_gate, int with_skip,
+                       int cond_channels, int precision, float* packed, pwv_stream_t stream);
+
+/* column order of P: map[col] = channel index into [filter(0..63) ‖ gate(64..127)] */
+int pwv_proj_column_map(int* map128);
+
+typedef struct pwv_layer_args {
+    int G;                                 /* nets in this launch (1 or 2) */
+    const float* x_in[PWV_MAX_NETS];       /* [N,T,64] */
+    float* x_out[PWV_MAX_NETS];            /* [N,T,64] */
+    const float* packed[PWV_MAX_NETS];     /* pwv_pack_layer_f32 output */
+    const float* proj[PWV_MAX_NETS];       /* P rows for THIS layer (128 floats each) */
+    int proj_row_stride;                   /* floats between consecutive P rows */
+    const float* cond;                     /* [N,T,cond_channels] or NULL */
+    int cond_channels;                     /* 0 or 80 */
+    float* skip[PWV_MAX_NETS];             /* [N,T,128] accumulators or NULL */
+    int skip_init;                         /* 1: skip = ..., 0: skip += ... */
+    int N, T, dilation;
+    int cond_hop, cond_offset, cond_frames;
+    int out_mode;                          /* PWV_OUT_RESIDUAL / PWV_OUT_GATED */
+    int precision;                         /* PWV_PREC_* */
+    int max_workgroups;                    /* 0 = one per CU */
+} pwv_layer_args;
+
+int pwv_wavenet_layer_f32(const pwv_layer_args* args, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * WaveNet post-processing head                                         modules.py:145-165
+ *   total = o @ skip_w + skip_bias   (in_mode PWV_HEAD_IN_GATED: use_skip_connection False,
+ *                                     only the last layer's skip is live, modules.py:147)
+ *   total = skip_sum                 (in_mode PWV_HEAD_IN_SKIPSUM)
+ *   y = relu(relu(total) @ post1 + b1) @ post2 + b2                    y [N,T,Q], Q <= 4
+ * ------------------------------------------------------------------------------------- */
+#define PWV_HEAD_IN_GATED 0
+#define PWV_HEAD_IN_SKIPSUM 1
+
+size_t pwv_head_packed_floats(int Q);
+/* skip [1,64,128], skip_bias [128]/NULL, post1 [1,128,128], post1_bias [128]/NULL,
+ * post2 [1,128,Q], post2_bias [Q]/NULL */
+int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* post1,
+                      const float* post1_bias, const float* post2, const float* post2_bias,
+                      int Q, int precision, float* packed, pwv_stream_t stream);
+
+typedef struct pwv_head_args {
+    int G;
+    const float* in[PWV_MAX_NETS];         /* [N,T,64] gated o, or [N,T,128] skip sum */
+    const float* packed[PWV_MAX_NETS];
+    float* out[PWV_MAX_NETS];              /* [N,T,Q] */
+    int N, T, Q;
+    int in_mode;
+    int precision;
+    int max_workgroups;
+} pwv_head_args;
+
+int pwv_wavenet_head_f32(const pwv_head_args* args, pwv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWV_HIP_H_ */

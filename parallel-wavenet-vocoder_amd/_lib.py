@@ -1,0 +1,149 @@
+"""ctypes binding of libpwv_hip.so (C ABI declared in include/pwv_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``build_library()`` here)
+with ``hipcc --offload-arch=gfx950``.  There is NO fallback: if the shared object is
+missing or a call fails, a ``PwvError`` is raised -- the product path never routes
+through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO_ROOT = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, 'libpwv_hip.so')
+CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_misc.hip')]
+
+PWV_MAX_NETS = 2
+PREC_F32, PREC_F16X3 = 0, 1
+OUT_RESIDUAL, OUT_GATED = 0, 1
+HEAD_IN_GATED, HEAD_IN_SKIPSUM = 0, 1
+
+# every symbol include/pwv_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = (
+    'pwv_last_error', 'pwv_version', 'pwv_device_cus', 'pwv_causal_conv_f32', 'pwv_linear_f32',
+    'pwv_upsample_repeat_f32', 'pwv_crop_time_f32', 'pwv_logistic_noise_f32', 'pwv_iaf_front_f32',
+    'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
+    'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32',
+)
+
+
+class PwvError(RuntimeError):
+    pass
+
+
+class LayerArgs(Structure):
+    _fields_ = [
+        ('G', c_int),
+        ('x_in', c_void_p * PWV_MAX_NETS),
+        ('x_out', c_void_p * PWV_MAX_NETS),
+        ('packed', c_void_p * PWV_MAX_NETS),
+        ('proj', c_void_p * PWV_MAX_NETS),
+        ('proj_row_stride', c_int),
+        ('cond', c_void_p),
+        ('cond_channels', c_int),
+        ('skip', c_void_p * PWV_MAX_NETS),
+        ('skip_init', c_int),
+        ('N', c_int), ('T', c_int), ('dilation', c_int),
+        ('cond_hop', c_int), ('cond_offset', c_int), ('cond_frames', c_int),
+        ('out_mode', c_int),
+        ('precision', c_int),
+        ('max_workgroups', c_int),
+    ]
+
+
+class HeadArgs(Structure):
+    _fields_ = [
+        ('G', c_int),
+        ('in_', c_void_p * PWV_MAX_NETS),
+        ('packed', c_void_p * PWV_MAX_NETS),
+        ('out', c_void_p * PWV_MAX_NETS),
+        ('N', c_int), ('T', c_int), ('Q', c_int),
+        ('in_mode', c_int),
+        ('precision', c_int),
+        ('max_workgroups', c_int),
+    ]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into the in-tree shared library."""
+    srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', 'pwv_common.h'), os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+            return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-I' + os.path.join(_REPO_ROOT, 'include'), '-I' + os.path.join(_PKG_DIR, 'csrc'),
+           '-o', LIB_PATH] + CSRC
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise PwvError('hipcc failed:\n' + res.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def _declare(lib):
+    f32p = c_void_p
+    lib.pwv_last_error.restype = c_char_p
+    lib.pwv_last_error.argtypes = []
+    lib.pwv_version.restype = c_int
+    lib.pwv_device_cus.restype = c_int
+    lib.pwv_causal_conv_f32.argtypes = [f32p, f32p, f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_linear_f32.argtypes = [f32p, f32p, f32p, f32p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_upsample_repeat_f32.argtypes = [f32p, f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_crop_time_f32.argtypes = [f32p, f32p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_logistic_noise_f32.argtypes = [f32p, c_int64, c_uint64, c_uint64, c_void_p]
+    lib.pwv_iaf_front_f32.argtypes = [f32p, f32p, f32p, c_int, f32p, c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                      c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_layer_packed_floats.restype = c_size_t
+    lib.pwv_layer_packed_floats.argtypes = [c_int, c_int]
+    lib.pwv_pack_layer_f32.argtypes = [f32p] * 8 + [c_int, c_int, c_int, f32p, c_void_p]
+    lib.pwv_proj_column_map.argtypes = [POINTER(c_int)]
+    lib.pwv_wavenet_layer_f32.argtypes = [POINTER(LayerArgs), c_void_p]
+    lib.pwv_head_packed_floats.restype = c_size_t
+    lib.pwv_head_packed_floats.argtypes = [c_int]
+    lib.pwv_pack_head_f32.argtypes = [f32p] * 6 + [c_int, c_int, f32p, c_void_p]
+    lib.pwv_wavenet_head_f32.argtypes = [POINTER(HeadArgs), c_void_p]
+    for name in EXPORTED_SYMBOLS:      # fails loudly (AttributeError) if a symbol is missing
+        getattr(lib, name)
+    return lib
+
+
+def lib():
+    """Load libpwv_hip.so (once).  Raises PwvError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PwvError('libpwv_hip.so not built at %s -- run `python -c "import __graft_entry__ as g; '
+                           'g.build()"` (hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's).  Load torch's first so our NEEDED entry binds to the runtime that owns the
+        # device context, streams and allocations we are handed.
+        import torch
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+        if os.path.exists(hip_rt):
+            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
+        try:
+            _lib = _declare(ctypes.CDLL(LIB_PATH))
+        except OSError as e:
+            raise PwvError('cannot load %s: %s' % (LIB_PATH, e))
+    return _lib
+
+
+def check(code: int, what: str = ''):
+    if code != 0:
+        msg = lib().pwv_last_error()
+        raise PwvError('%s failed (%d): %s' % (what or 'libpwv_hip call', code, msg.decode() if msg else '?'))
+
+
+def proj_column_map():
+    arr = (c_int * 128)()
+    check(lib().pwv_proj_column_map(arr), 'pwv_proj_column_map')
+    return list(arr)

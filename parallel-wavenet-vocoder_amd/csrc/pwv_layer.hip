@@ -1,0 +1,696 @@
+// Fused gated-residual WaveNet layer and post-processing head for gfx950 (MI355X).
+//
+// Replaces, per layer, the ~15 TensorFlow ops of WaveNet._create_dilation_layer
+// (/root/reference/modules.py:185-259) and, per net, the post-processing of
+// WaveNet.__call__ (modules.py:145-165).
+//
+// Design:
+//   * GEMM orientation: MFMA rows = output channels, MFMA columns = time.  A wave owns 32
+//     consecutive samples; lane (t = lane&31, h = lane>>5) owns, of every 64-channel row, the
+//     16-byte chunks at float offsets 8g + 4h -- which is exactly the v_mfma 32x32 C/D layout
+//     (pwv::chan_of).  Hence x[t], x[t-d] are loaded straight from HBM into the B operand,
+//     the gated output o stays in the registers it was accumulated in and IS the B operand of
+//     the dense / skip GEMMs, and the residual add is a register add.  No LDS round trip and
+//     no transposes for activations.
+//   * Weights are the A operand, pre-packed (pwv_pack_*) so each lane reads 4 consecutive
+//     k-steps with one conflict-free ds_read_b128; a workgroup loads one layer's weights
+//     (80-152 KB of the 160 KB LDS) once and walks many time tiles (persistent over tiles).
+//   * The conditioning term and the filter/gate biases enter as the accumulator's initial
+//     value (frame-rate projection P), so the hoisted 'repeat' conditioning costs no FLOPs
+//     in this kernel; per-sample conditioning (transposed-conv upsampling) adds 40 k-steps.
+//   * fp32 arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains, 157 TFLOP/s peak).
+#include "pwv_common.h"
+
+namespace pwv {
+
+// ---- packed layer layout (floats) ----------------------------------------------------
+constexpr int kA1 = 0;                    // [4 it][16 ks4][64 lane][4]   filter‖gate, K = 128
+constexpr int kA1Size = 4 * 16 * 64 * 4;  // 16384
+constexpr int kA2 = kA1 + kA1Size;        // [2 it][8 ks4][64][4]         dense, K = 64
+constexpr int kA2Size = 2 * 8 * 64 * 4;   // 4096
+constexpr int kBD = kA2 + kA2Size;        // [2 h][32]                    dense bias (D layout)
+constexpr int kBDSize = 64;
+constexpr int kLayerBase = kBD + kBDSize;  // 20544
+constexpr int kASSize = 4 * 8 * 64 * 4;    // 8192   skip, K = 64, 128 outputs
+constexpr int kBSSize = 128;               // [2 h][64]
+constexpr int kCondC = 80;                 // per-sample conditioning channels supported
+constexpr int kACSize = 4 * (kCondC / 8) * 64 * 4;  // 10240
+
+constexpr int layer_floats(bool skip, bool cond) {
+    return kLayerBase + (skip ? kASSize + kBSSize : 0) + (cond ? kACSize : 0);
+}
+
+// ---- packed head layout ----------------------------------------------------------------
+constexpr int kHAS = 0;                       // skip weights (as above)
+constexpr int kHBS = kHAS + kASSize;          // skip bias
+constexpr int kHA1 = kHBS + kBSSize;          // post1 [4 it][16 ks4][64][4]
+constexpr int kHA1Size = 4 * 16 * 64 * 4;
+constexpr int kHB1 = kHA1 + kHA1Size;         // post1 bias [2 h][64]
+constexpr int kHW2 = kHB1 + 128;              // post2 [2 h][Q][64], then bias [Q] (padded to 4)
+constexpr int kMaxQ = 4;
+constexpr int head_floats(int Q) { return kHW2 + 2 * Q * 64 + 4; }
+
+struct LayerParams {
+    const float* x_in[PWV_MAX_NETS];
+    float* x_out[PWV_MAX_NETS];
+    const float* packed[PWV_MAX_NETS];
+    const float* proj[PWV_MAX_NETS];
+    float* skip[PWV_MAX_NETS];
+    const float* cond;
+    int proj_row_stride;
+    int G, N, T, dilation;
+    int cond_hop, cond_offset, cond_frames;
+    int skip_init;
+};
+
+struct HeadParams {
+    const float* in[PWV_MAX_NETS];
+    const float* packed[PWV_MAX_NETS];
+    float* out[PWV_MAX_NETS];
+    int G, N, T, Q;
+};
+
+__device__ __forceinline__ float gate_act(float f, float g) {
+    // tanh(f) * sigmoid(g) = (1 - e^-2f) / ((1 + e^-2f)(1 + e^-g)); one v_rcp, two v_exp.
+    // clamps keep the product of the denominators finite; tanh(+-20) == +-1 in fp32,
+    // sigmoid(-40) = 4e-18.
+    f = fminf(fmaxf(f, -20.f), 20.f);
+    g = fminf(fmaxf(g, -40.f), 40.f);
+    const float e1 = __builtin_amdgcn_exp2f(f * -2.8853900817779268f);
+    const float e2 = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
+}
+
+// lane (t,h) loads its NCH 16-byte chunks (float offsets 8g + 4h) of one channels-last row
+template <int NCH>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int h, bool valid, float (&dst)[4 * NCH]) {
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (valid) v = *reinterpret_cast<const f32x4*>(row + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * g + e] = v[e];
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_contig(const float* __restrict__ p, bool valid, float (&dst)[4 * NCH]) {
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (valid) v = *reinterpret_cast<const f32x4*>(p + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * g + e] = v[e];
+    }
+}
+
+template <bool SKIP, bool COND>
+struct TileRegs {
+    float xb[32];                 // x[t-d], this lane's 32 channels
+    float xc[32];                 // x[t]
+    float pj[64];                 // P[frame(t)] : accumulator init for the 4 F/G row tiles
+    float cd[COND ? 40 : 4];      // cond[t], this lane's 40 channels
+    float sk[SKIP ? 64 : 4];      // running skip sum (D layout)
+    int row;                      // flattened row n*T + t of this lane
+    bool valid;
+};
+
+template <bool SKIP, bool COND>
+__device__ __forceinline__ void load_tile(const LayerParams& p, int net, int tile, int wave, int lane,
+                                          TileRegs<SKIP, COND>& r, bool skip_load) {
+    const int h = lane >> 5;
+    const int rows = p.N * p.T;
+    const int row = tile * 128 + wave * 32 + (lane & 31);
+    r.row = row;
+    r.valid = row < rows;
+    const int n = row / p.T;
+    const int t = row - n * p.T;
+    const float* xrow = p.x_in[net] + (size_t)row * 64;
+    load_row<8>(xrow, h, r.valid, r.xc);
+    load_row<8>(xrow - (size_t)p.dilation * 64, h, r.valid && (t >= p.dilation), r.xb);
+    int prow = 0;
+    if (p.cond_hop > 0) prow = n * p.cond_frames + (t + p.cond_offset) / p.cond_hop;
+    load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.valid, r.pj);
+    if constexpr (COND) load_row<10>(p.cond + (size_t)row * kCondC, h, r.valid, r.cd);
+    if constexpr (SKIP) {
+        // skip row [128]: chunk for (it, q) at float offset 32*it + 8*q + 4*h
+        if (skip_load) {
+            const float* srow = p.skip[net] + (size_t)row * 128;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (r.valid) v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r.sk[it * 16 + q * 4 + e] = v[e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) r.sk[i] = 0.f;
+        }
+    }
+}
+
+// lds fragment: 4 consecutive k-steps of row tile `it` for this lane (one ds_read_b128)
+__device__ __forceinline__ f32x4 frag(const float* lds, int base, int it, int ngroups, int g, int lane) {
+    return *reinterpret_cast<const f32x4*>(&lds[base + ((it * ngroups + g) * 64 + lane) * 4]);
+}
+
+// One GEMM as NG groups of (NIT row tiles x 4 k-steps) MFMAs.  The A fragments of group g+1
+// are read while group g's MFMAs issue; sched_barrier(0) pins that order so the scheduler
+// cannot hoist all ds_reads (which spills).  `a` enters holding group 0's fragments and leaves
+// holding whatever `tail(a)` loaded during the last group (the next GEMM's group 0).
+//   bval(ks): B register of k-step ks;  extra(g): VALU work to overlap with group g's MFMAs.
+template <int NG, int NIT, int IT0, int ITSTEP, int NACC, typename BF, typename EF, typename TF>
+__device__ __forceinline__ void gemm_groups(const float* lds, int base, int lane, f32x16 (&acc)[NACC], f32x4 (&a)[4],
+                                            BF&& bval, EF&& extra, TF&& tail) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        f32x4 n[4] = {a[0], a[1], a[2], a[3]};
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) n[i] = frag(lds, base, IT0 + i * ITSTEP, NG, g + 1, lane);
+        } else {
+            tail(n);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float b = bval(g * 4 + e);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b, acc[IT0 + i * ITSTEP], 0, 0, 0);
+        }
+        extra(g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = n[i];
+    }
+}
+
+template <bool SKIP, bool COND, bool GATED>
+__global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
+    constexpr int kLds = layer_floats(SKIP, COND);
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int net = blockIdx.x % p.G;
+    const int wg = blockIdx.x / p.G;
+    const int nwg = gridDim.x / p.G;
+
+    {   // one layer's weights -> LDS (packed order == LDS order)
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < kLds / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    constexpr int kAS = kLayerBase;
+    constexpr int kBS = kAS + kASSize;
+    constexpr int kAC = kLayerBase + (SKIP ? kASSize + kBSSize : 0);
+    constexpr int NC8 = kCondC / 8;
+
+    const int rows = p.N * p.T;
+    const int ntiles = (rows + 127) / 128;
+    const bool skip_load = SKIP && !p.skip_init;
+
+    int tile = wg;
+    TileRegs<SKIP, COND> cur;
+    load_tile<SKIP, COND>(p, net, tile, wave, lane, cur, skip_load);
+
+    auto no_extra = [](int) {};
+
+    while (tile < ntiles) {
+        const int next = tile + nwg;
+        // ---- GEMM1: [F;G][128 x 32t] = W1^T[128 x K] * [x[t-d]; x[t]; (cond[t])] -------------
+        // accumulators start at P[frame(t)] (conditioning projection + filter/gate bias)
+        f32x16 acc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][r] = cur.pj[it * 16 + r];
+        float o[32];
+        f32x4 a[4];
+        auto bx = [&](int ks) -> float { return ks < 32 ? cur.xb[ks] : cur.xc[ks - 32]; };
+        auto bc = [&](int ks) -> float { return cur.cd[COND ? ks : 0]; };
+        // pair 0 = row tiles (0: F[0:32], 2: G[0:32]); pair 1 = (1: F[32:64], 3: G[32:64]).
+        // pair 0 is gated on the VALU while pair 1's MFMAs run.
+        if constexpr (COND) {
+            a[0] = frag(lds, kAC, 0, NC8, 0, lane);
+            a[1] = frag(lds, kAC, 2, NC8, 0, lane);
+            gemm_groups<NC8, 2, 0, 2>(lds, kAC, lane, acc, a, bc, no_extra, [&](f32x4(&n)[4]) {
+                n[0] = frag(lds, kA1, 0, 16, 0, lane);
+                n[1] = frag(lds, kA1, 2, 16, 0, lane);
+            });
+        } else {
+            a[0] = frag(lds, kA1, 0, 16, 0, lane);
+            a[1] = frag(lds, kA1, 2, 16, 0, lane);
+        }
+        gemm_groups<16, 2, 0, 2>(lds, kA1, lane, acc, a, bx, no_extra, [&](f32x4(&n)[4]) {
+            if constexpr (COND) {
+                n[0] = frag(lds, kAC, 1, NC8, 0, lane);
+                n[1] = frag(lds, kAC, 3, NC8, 0, lane);
+            } else {
+                n[0] = frag(lds, kA1, 1, 16, 0, lane);
+                n[1] = frag(lds, kA1, 3, 16, 0, lane);
+            }
+        });
+        if constexpr (COND) {
+            gemm_groups<NC8, 2, 1, 2>(lds, kAC, lane, acc, a, bc, no_extra, [&](f32x4(&n)[4]) {
+                n[0] = frag(lds, kA1, 1, 16, 0, lane);
+                n[1] = frag(lds, kA1, 3, 16, 0, lane);
+            });
+        }
+        gemm_groups<16, 2, 1, 2>(
+            lds, kA1, lane, acc, a, bx, [&](int g) { o[g] = gate_act(acc[0][g], acc[2][g]); },
+            [&](f32x4(&n)[4]) {
+                if constexpr (!GATED) {
+                    n[0] = frag(lds, kA2, 0, 8, 0, lane);
+                    n[1] = frag(lds, kA2, 1, 8, 0, lane);
+                } else if constexpr (SKIP) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) n[i] = frag(lds, kAS, i, 8, 0, lane);
+                }
+            });
+
+        // next tile's operands: in flight during GEMM2 / skip GEMM / stores
+        TileRegs<SKIP, COND> nx;   // rows past the end are predicated off inside load_tile
+        load_tile<SKIP, COND>(p, net, next, wave, lane, nx, skip_load);
+        __builtin_amdgcn_sched_barrier(0);
+
+        float* orow = p.x_out[net] + (size_t)cur.row * 64;
+        if constexpr (GATED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+            if (cur.valid) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                }
+            }
+        } else {
+            // ---- GEMM2: dense 64 -> 64, accumulator starts at x[t] + dense_bias ---------------
+            f32x16 acc2[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bd = *reinterpret_cast<const f32x4*>(&lds[kBD + h * 32 + it * 16 + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = cur.xc[it * 16 + q * 4 + e] + bd[e];
+                }
+            }
+            // k-steps 0..15 use o tile 0 (ready); pair 1 is gated under those MFMAs
+            gemm_groups<8, 2, 0, 1>(
+                lds, kA2, lane, acc2, a, [&](int ks) -> float { return o[ks]; },
+                [&](int g) {
+                    if (g < 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[16 + 4 * g + e] = gate_act(acc[1][4 * g + e], acc[3][4 * g + e]);
+                    }
+                },
+                [&](f32x4(&n)[4]) {
+                    if constexpr (SKIP) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) n[i] = frag(lds, kAS, i, 8, 0, lane);
+                    }
+                });
+            if (cur.valid) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int it = g >> 2, q = g & 3;
+                    f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                }
+            }
+        }
+
+        if constexpr (SKIP) {
+            // ---- skip 64 -> 128, accumulated across layers (modules.py:243-250, :147) ----------
+            f32x16 accs[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kBS + h * 64 + it * 16 + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = cur.sk[it * 16 + q * 4 + e] + bs[e];
+                }
+            gemm_groups<8, 4, 0, 1>(lds, kAS, lane, accs, a, [&](int ks) -> float { return o[ks]; }, no_extra,
+                                    [](f32x4(&)[4]) {});
+            if (cur.valid) {
+                float* srow = p.skip[net] + (size_t)cur.row * 128;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(srow + 32 * it + 8 * q + 4 * h) = v;
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        tile = next;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Head: (o @ skip + b | skip_sum) -> relu -> post1 -> relu -> post2     modules.py:145-165
+// --------------------------------------------------------------------------------------
+template <bool FROM_GATED>
+__global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
+    constexpr int kLds = head_floats(kMaxQ);
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int net = blockIdx.x % p.G;
+    const int wg = blockIdx.x / p.G;
+    const int nwg = gridDim.x / p.G;
+    const int Q = p.Q;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        const int n4 = head_floats(Q) / 4;
+        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    auto no_extra = [](int) {};
+    const int rows = p.N * p.T;
+    const int ntiles = (rows + 127) / 128;
+    for (int tile = wg; tile < ntiles; tile += nwg) {
+        const int row = tile * 128 + wave * 32 + (lane & 31);
+        const bool valid = row < rows;
+        f32x16 accs[4];
+        f32x4 a[4];
+        if constexpr (FROM_GATED) {
+            float o[32];
+            load_row<8>(p.in[net] + (size_t)row * 64, h, valid, o);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kHBS + h * 64 + it * 16 + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = bs[e];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag(lds, kHAS, i, 8, 0, lane);
+            gemm_groups<8, 4, 0, 1>(lds, kHAS, lane, accs, a, [&](int ks) -> float { return o[ks]; }, no_extra,
+                                    [&](f32x4(&n)[4]) {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) n[i] = frag(lds, kHA1, i, 16, 0, lane);
+                                    });
+        } else {
+            const float* srow = p.in[net] + (size_t)row * 128;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (valid) v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag(lds, kHA1, i, 16, 0, lane);
+        }
+        // relu -> post1 (128 -> 128)
+        f32x16 acc1[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&lds[kHB1 + h * 64 + it * 16 + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = b1[e];
+            }
+        gemm_groups<16, 4, 0, 1>(
+            lds, kHA1, lane, acc1, a, [&](int ks) -> float { return fmaxf(accs[ks >> 4][ks & 15], 0.f); }, no_extra,
+            [](f32x4(&)[4]) {});
+        // relu -> post2 (128 -> Q): per-lane partial dot over its 64 channels, then add the halves
+        for (int q = 0; q < Q; ++q) {
+            float part = 0.f;
+            const float* w2 = &lds[kHW2 + (h * Q + q) * 64];
+#pragma unroll
+            for (int i4 = 0; i4 < 16; ++i4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + 4 * i4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * i4 + e;
+                    part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[e], part);
+                }
+            }
+            part += __shfl_xor(part, 32);
+            part += lds[kHW2 + 2 * Q * 64 + q];
+            if (valid && h == 0) p.out[net][(size_t)row * Q + q] = part;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// weight packing (device-side gathers from TensorFlow layouts)
+// --------------------------------------------------------------------------------------
+__global__ void pack_layer_kernel(const float* filter, const float* gate, const float* dense,
+                                  const float* dense_bias, const float* skip, const float* skip_bias,
+                                  const float* gc_filter, const float* gc_gate, int with_skip, int cond_c,
+                                  float* out, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float v = 0.f;
+    int i = idx;
+    if (i < kA1Size) {
+        const int e = i & 3, lane = (i >> 2) & 63, ks4 = (i >> 8) & 15, it = i >> 12;
+        const int ks = ks4 * 4 + e, tap = ks >> 5, r = ks & 31, h = lane >> 5;
+        const int cin = 8 * (r >> 2) + 4 * h + (r & 3);
+        const int oc = 32 * it + (lane & 31);
+        v = oc < 64 ? filter[(tap * 64 + cin) * 64 + oc] : gate[(tap * 64 + cin) * 64 + oc - 64];
+    } else if ((i -= kA1Size) < kA2Size) {
+        const int e = i & 3, lane = (i >> 2) & 63, ks4 = (i >> 8) & 7, it = i >> 11;
+        const int ks = ks4 * 4 + e, h = lane >> 5;
+        const int c = chan_of(ks >> 4, ks & 15, h);
+        v = dense[c * 64 + 32 * it + (lane & 31)];
+    } else if ((i -= kA2Size) < kBDSize) {
+        const int h = i >> 5, it = (i >> 4) & 1, r = i & 15;
+        v = dense_bias ? dense_bias[chan_of(it, r, h)] : 0.f;
+    } else {
+        i -= kBDSize;
+        bool done = false;
+        if (with_skip) {
+            if (i < kASSize) {
+                const int e = i & 3, lane = (i >> 2) & 63, ks4 = (i >> 8) & 7, it = i >> 11;
+                const int ks = ks4 * 4 + e, h = lane >> 5;
+                const int c = chan_of(ks >> 4, ks & 15, h);
+                v = skip[c * 128 + 32 * it + (lane & 31)];
+                done = true;
+            } else if ((i -= kASSize) < kBSSize) {
+                const int h = i >> 6, it = (i >> 4) & 3, r = i & 15;
+                v = skip_bias ? skip_bias[chan_of(it, r, h)] : 0.f;
+                done = true;
+            } else {
+                i -= kBSSize;
+            }
+        }
+        if (!done && cond_c > 0) {
+            const int nc8 = cond_c / 8;
+            const int e = i & 3, lane = (i >> 2) & 63;
+            const int rest = i >> 8;  // it * nc8 + ks4
+            const int ks4 = rest % nc8, it = rest / nc8;
+            const int r = ks4 * 4 + e, h = lane >> 5;
+            const int ci = 8 * (r >> 2) + 4 * h + (r & 3);
+            const int oc = 32 * it + (lane & 31);
+            v = oc < 64 ? gc_filter[ci * 64 + oc] : gc_gate[ci * 64 + oc - 64];
+        }
+    }
+    out[idx] = v;
+}
+
+__global__ void pack_head_kernel(const float* skip, const float* skip_bias, const float* post1,
+                                 const float* post1_bias, const float* post2, const float* post2_bias, int Q,
+                                 float* out, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float v = 0.f;
+    int i = idx;
+    if (i < kASSize) {
+        const int e = i & 3, lane = (i >> 2) & 63, ks4 = (i >> 8) & 7, it = i >> 11;
+        const int ks = ks4 * 4 + e, h = lane >> 5;
+        v = skip ? skip[chan_of(ks >> 4, ks & 15, h) * 128 + 32 * it + (lane & 31)] : 0.f;
+    } else if ((i -= kASSize) < kBSSize) {
+        const int h = i >> 6, it = (i >> 4) & 3, r = i & 15;
+        v = skip_bias ? skip_bias[chan_of(it, r, h)] : 0.f;
+    } else if ((i -= kBSSize) < kHA1Size) {
+        const int e = i & 3, lane = (i >> 2) & 63, ks4 = (i >> 8) & 15, it = i >> 12;
+        const int ks = ks4 * 4 + e, h = lane >> 5;
+        v = post1[chan_of(ks >> 4, ks & 15, h) * 128 + 32 * it + (lane & 31)];
+    } else if ((i -= kHA1Size) < 128) {
+        const int h = i >> 6, it = (i >> 4) & 3, r = i & 15;
+        v = post1_bias ? post1_bias[chan_of(it, r, h)] : 0.f;
+    } else if ((i -= 128) < 2 * Q * 64) {
+        const int j = i & 63, hq = i >> 6;
+        const int q = hq % Q, h = hq / Q;
+        v = post2[chan_of(j >> 4, j & 15, h) * Q + q];
+    } else {
+        i -= 2 * Q * 64;
+        v = (i < Q && post2_bias) ? post2_bias[i] : 0.f;
+    }
+    out[idx] = v;
+}
+
+template <bool SKIP, bool COND, bool GATED>
+static int launch_layer(const LayerParams& lp, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((layer_f32_kernel<SKIP, COND, GATED>), dim3(grid), dim3(256), 0, s, lp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "layer kernel launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+}  // namespace pwv
+
+using namespace pwv;
+
+extern "C" {
+
+size_t pwv_layer_packed_floats(int with_skip, int cond_channels) {
+    return (size_t)layer_floats(with_skip != 0, cond_channels > 0);
+}
+
+size_t pwv_head_packed_floats(int Q) { return (size_t)head_floats(Q); }
+
+int pwv_proj_column_map(int* map128) {
+    if (!map128) return set_error(PWV_EINVAL, "map128 is NULL");
+    for (int h = 0; h < 2; ++h)
+        for (int it = 0; it < 4; ++it)
+            for (int r = 0; r < 16; ++r) map128[h * 64 + it * 16 + r] = chan_of(it, r, h);
+    return PWV_OK;
+}
+
+int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dense, const float* dense_bias,
+                       const float* skip, const float* skip_bias, const float* gc_filter, const float* gc_gate,
+                       int with_skip, int cond_channels, int precision, float* packed, pwv_stream_t stream) {
+    PWV_CHECK_ARG(filter && gate && dense && packed, "pwv_pack_layer_f32: NULL weight pointer");
+    PWV_CHECK_ARG(!with_skip || skip, "pwv_pack_layer_f32: with_skip needs skip weights");
+    PWV_CHECK_ARG(cond_channels == 0 || cond_channels == kCondC,
+                  "pwv_pack_layer_f32: per-sample conditioning supports %d channels, got %d", kCondC, cond_channels);
+    PWV_CHECK_ARG(cond_channels == 0 || (gc_filter && gc_gate), "pwv_pack_layer_f32: gc weights missing");
+    PWV_CHECK_ARG(precision == PWV_PREC_F32, "pwv_pack_layer_f32: unsupported precision %d", precision);
+    const int total = layer_floats(with_skip != 0, cond_channels > 0);
+    hipLaunchKernelGGL(pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, filter, gate,
+                       dense, dense_bias, skip, skip_bias, gc_filter, gc_gate, with_skip, cond_channels, packed, total);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* post1, const float* post1_bias,
+                      const float* post2, const float* post2_bias, int Q, int precision, float* packed,
+                      pwv_stream_t stream) {
+    PWV_CHECK_ARG(post1 && post2 && packed, "pwv_pack_head_f32: NULL weight pointer");
+    PWV_CHECK_ARG(Q >= 1 && Q <= kMaxQ, "pwv_pack_head_f32: Q must be in [1,%d], got %d", kMaxQ, Q);
+    PWV_CHECK_ARG(precision == PWV_PREC_F32, "pwv_pack_head_f32: unsupported precision %d", precision);
+    const int total = head_floats(Q);
+    hipLaunchKernelGGL(pack_head_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, skip, skip_bias,
+                       post1, post1_bias, post2, post2_bias, Q, packed, total);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
+    PWV_CHECK_ARG(a, "pwv_wavenet_layer_f32: args is NULL");
+    PWV_CHECK_ARG(a->G >= 1 && a->G <= PWV_MAX_NETS, "pwv_wavenet_layer_f32: G=%d out of range", a->G);
+    PWV_CHECK_ARG(a->N >= 1 && a->T >= 1 && a->dilation >= 1, "pwv_wavenet_layer_f32: bad N/T/dilation");
+    PWV_CHECK_ARG((long long)a->N * a->T < (1ll << 31) - 256, "pwv_wavenet_layer_f32: N*T too large");
+    PWV_CHECK_ARG(a->precision == PWV_PREC_F32, "pwv_wavenet_layer_f32: unsupported precision %d", a->precision);
+    PWV_CHECK_ARG(a->cond_channels == 0 || a->cond_channels == kCondC,
+                  "pwv_wavenet_layer_f32: per-sample conditioning supports %d channels", kCondC);
+    PWV_CHECK_ARG((a->cond_channels > 0) == (a->cond != nullptr), "pwv_wavenet_layer_f32: cond / cond_channels mismatch");
+    PWV_CHECK_ARG(a->proj_row_stride % 4 == 0, "pwv_wavenet_layer_f32: proj_row_stride must be a multiple of 4");
+    PWV_CHECK_ARG(a->cond_hop >= 0, "pwv_wavenet_layer_f32: cond_hop < 0");
+    LayerParams lp{};
+    bool any_skip = false;
+    for (int g = 0; g < a->G; ++g) {
+        PWV_CHECK_ARG(a->x_in[g] && a->x_out[g] && a->packed[g] && a->proj[g],
+                      "pwv_wavenet_layer_f32: NULL buffer for net %d", g);
+        PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_layer_f32: in-place layers are not supported (x[t-d] halo)");
+        lp.x_in[g] = a->x_in[g];
+        lp.x_out[g] = a->x_out[g];
+        lp.packed[g] = a->packed[g];
+        lp.proj[g] = a->proj[g];
+        lp.skip[g] = a->skip[g];
+        any_skip = any_skip || a->skip[g];
+    }
+    for (int g = 0; g < a->G; ++g)
+        PWV_CHECK_ARG(!any_skip || a->skip[g], "pwv_wavenet_layer_f32: skip must be set for all nets or none");
+    lp.cond = a->cond;
+    lp.proj_row_stride = a->proj_row_stride;
+    lp.G = a->G;
+    lp.N = a->N;
+    lp.T = a->T;
+    lp.dilation = a->dilation;
+    lp.cond_hop = a->cond_hop;
+    lp.cond_offset = a->cond_offset;
+    lp.cond_frames = a->cond_frames;
+    lp.skip_init = a->skip_init;
+
+    const int cus = device_cus();
+    if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
+    const long long rows = (long long)a->N * a->T;
+    const int ntiles = (int)((rows + 127) / 128);
+    int per_net = (a->max_workgroups > 0 ? a->max_workgroups : cus) / a->G;
+    if (per_net < 1) per_net = 1;
+    if (per_net > ntiles) per_net = ntiles;
+    const int grid = per_net * a->G;
+    hipStream_t s = (hipStream_t)stream;
+    const bool cond = a->cond != nullptr, gated = a->out_mode == PWV_OUT_GATED;
+    PWV_CHECK_ARG(a->out_mode == PWV_OUT_GATED || a->out_mode == PWV_OUT_RESIDUAL, "pwv_wavenet_layer_f32: bad out_mode");
+    if (any_skip) {
+        if (cond) return gated ? launch_layer<true, true, true>(lp, grid, s) : launch_layer<true, true, false>(lp, grid, s);
+        return gated ? launch_layer<true, false, true>(lp, grid, s) : launch_layer<true, false, false>(lp, grid, s);
+    }
+    if (cond) return gated ? launch_layer<false, true, true>(lp, grid, s) : launch_layer<false, true, false>(lp, grid, s);
+    return gated ? launch_layer<false, false, true>(lp, grid, s) : launch_layer<false, false, false>(lp, grid, s);
+}
+
+int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
+    PWV_CHECK_ARG(a, "pwv_wavenet_head_f32: args is NULL");
+    PWV_CHECK_ARG(a->G >= 1 && a->G <= PWV_MAX_NETS, "pwv_wavenet_head_f32: G=%d out of range", a->G);
+    PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_head_f32: bad N/T");
+    PWV_CHECK_ARG((long long)a->N * a->T < (1ll << 31) - 256, "pwv_wavenet_head_f32: N*T too large");
+    PWV_CHECK_ARG(a->Q >= 1 && a->Q <= kMaxQ, "pwv_wavenet_head_f32: Q must be in [1,%d]", kMaxQ);
+    PWV_CHECK_ARG(a->precision == PWV_PREC_F32, "pwv_wavenet_head_f32: unsupported precision %d", a->precision);
+    PWV_CHECK_ARG(a->in_mode == PWV_HEAD_IN_GATED || a->in_mode == PWV_HEAD_IN_SKIPSUM, "pwv_wavenet_head_f32: bad in_mode");
+    HeadParams hp{};
+    for (int g = 0; g < a->G; ++g) {
+        PWV_CHECK_ARG(a->in[g] && a->packed[g] && a->out[g], "pwv_wavenet_head_f32: NULL buffer for net %d", g);
+        hp.in[g] = a->in[g];
+        hp.packed[g] = a->packed[g];
+        hp.out[g] = a->out[g];
+    }
+    hp.G = a->G;
+    hp.N = a->N;
+    hp.T = a->T;
+    hp.Q = a->Q;
+    const int cus = device_cus();
+    if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
+    const long long rows = (long long)a->N * a->T;
+    const int ntiles = (int)((rows + 127) / 128);
+    int per_net = (a->max_workgroups > 0 ? a->max_workgroups : cus) / a->G;
+    if (per_net < 1) per_net = 1;
+    if (per_net > ntiles) per_net = ntiles;
+    const int grid = per_net * a->G;
+    if (a->in_mode == PWV_HEAD_IN_GATED)
+        hipLaunchKernelGGL((head_f32_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, hp);
+    else
+        hipLaunchKernelGGL((head_f32_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, hp);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+}  // extern "C"

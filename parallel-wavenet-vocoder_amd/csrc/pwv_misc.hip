@@ -1,0 +1,319 @@
+// Small kernels around the fused layer: generic causal_conv, the frame-rate GEMM,
+// condition upsampling (repeat / crop), logistic noise, IAF affine + causal layer.
+// gfx950 only.  Reference call sites are cited per kernel (file:line in /root/reference).
+#include "pwv_common.h"
+
+#include <cstring>
+
+namespace pwv {
+
+static thread_local char g_err[512] = {0};
+char* error_buffer() { return g_err; }
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// --------------------------------------------------------------------------------------
+// modules.causal_conv (modules.py:11-43), any W / Cin / Cout / dilation.
+// One thread per (row, 4 output channels); x[row - shift] is a wave-broadcast read, the filter
+// row read is coalesced over the output channels.  API-parity op (the fused layer kernel is
+// the hot path); memory-bound for small Cin.
+// --------------------------------------------------------------------------------------
+__global__ void causal_conv_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
+                                   int N, int T, int Cin, int Cout, int W, int d) {
+    const int co4 = (Cout + 3) / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * T * co4;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % co4);
+    const long long row = idx / co4;
+    const int t = (int)(row % T);
+    const int co = c4 * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < W; ++k) {
+        const long long shift = (long long)(W - 1 - k) * d;
+        if (shift > t) continue;
+        const float* xr = x + (row - shift) * Cin;
+        const float* fk = f + (size_t)k * Cin * Cout;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xr[ci];
+            const float* fr = fk + (size_t)ci * Cout + co;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co + e < Cout) acc[e] = fmaf(xv, fr[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (co + e < Cout) y[row * Cout + co + e] = acc[e];
+}
+
+// --------------------------------------------------------------------------------------
+// y[M,Nout] = act(x[M,K] @ w[K,Nout] + bias): fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// MFMA rows = output columns n, MFMA columns = rows m; a wave owns 32 rows m and keeps its
+// x rows in registers (lane (m,h) holds k in [h*K/2, (h+1)*K/2)), then walks 128-wide column
+// blocks; the weight A operand is read straight from global (coalesced over n, L1/L2 hits).
+// models.py:110-120,128-130 and the hoisted modules.py:216-228.
+// --------------------------------------------------------------------------------------
+template <int KH4>  // K/2 in units of 4 floats (K = 8*KH4)
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                     int K, int Nout, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int m = (blockIdx.x * 4 + wave) * 32 + j;
+    const bool mvalid = m < M;
+    const int kh = K / 2;
+    float xb[KH4 * 4];
+#pragma unroll
+    for (int g = 0; g < KH4; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (mvalid && 4 * g < kh) v = *reinterpret_cast<const f32x4*>(x + (size_t)m * K + h * kh + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xb[4 * g + e] = v[e];
+    }
+    for (int n0 = blockIdx.y * 128; n0 < Nout; n0 += gridDim.y * 128) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + chan_of(it, r, h);
+                acc[it][r] = (bias && n < Nout) ? bias[n] : 0.f;
+            }
+#pragma unroll
+        for (int ks = 0; ks < KH4 * 4; ++ks) {
+            if (ks < kh) {
+                const float* wr = w + (size_t)(h * kh + ks) * Nout + n0 + j;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float a = (n0 + 32 * it + j < Nout) ? wr[32 * it] : 0.f;
+                    acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[ks], acc[it], 0, 0, 0);
+                }
+            }
+        }
+        if (mvalid) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + 32 * it + 8 * q + 4 * h;
+                    if (n < Nout) {
+                        f32x4 v = {acc[it][q * 4], acc[it][q * 4 + 1], acc[it][q * 4 + 2], acc[it][q * 4 + 3]};
+                        if (relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        *reinterpret_cast<f32x4*>(y + (size_t)m * Nout + n) = v;
+                    }
+                }
+        }
+    }
+}
+
+// models.py:131-133: out[n,t,:] = frames[n,(t+offset)/hop,:]
+__global__ void upsample_repeat_kernel(const float* __restrict__ frames, float* __restrict__ out, int N, int t_mel,
+                                       int C4, int T, int hop, int offset) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * T * C4;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4);
+    const long long row = idx / C4;
+    const int t = (int)(row % T);
+    const int n = (int)(row / T);
+    int fr = (t + offset) / hop;
+    fr = fr < t_mel ? fr : t_mel - 1;
+    reinterpret_cast<f32x4*>(out)[idx] = reinterpret_cast<const f32x4*>(frames)[((size_t)n * t_mel + fr) * C4 + c];
+}
+
+// models.py:124: out[n,t,:] = in[n,t+offset,:]
+__global__ void crop_time_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int T_in, int C4,
+                                 int T_out, int offset) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * T_out * C4;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4);
+    const long long row = idx / C4;
+    const int t = (int)(row % T_out);
+    const int n = (int)(row / T_out);
+    reinterpret_cast<f32x4*>(out)[idx] = reinterpret_cast<const f32x4*>(in)[((size_t)n * T_in + t + offset) * C4 + c];
+}
+
+// models.py:32-33: Logistic(0,1) sample = log u - log1p(-u); u from a splitmix64 counter hash
+__global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsigned long long seed,
+                                      unsigned long long offset) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i + offset;
+    s += 0x9E3779B97F4A7C15ull;
+    s = (s ^ (s >> 30)) * 0xBF58476D1CE4E5B9ull;
+    s = (s ^ (s >> 27)) * 0x94D049BB133111EBull;
+    s = s ^ (s >> 31);
+    // 24 random bits -> u in (0,1), never 0 or 1
+    const float u = ((float)(unsigned)(s >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    z[i] = logf(u) - log1pf(-u);
+}
+
+// modules.py:59 (x = z*s + b) fused with the next flow's causal layer (modules.py:179-180):
+// h_g[row, c] = sum_k x[t-(W-1-k)] * filt_g[k,0,c].  One thread per (row, 4 channels).
+struct FrontParams {
+    const float* z;
+    const float* s;
+    const float* b;
+    float* x_out;
+    const float* filt[PWV_MAX_NETS];
+    float* h[PWV_MAX_NETS];
+    int sb_stride, G, N, T, W, R;
+};
+
+__global__ void iaf_front_kernel(const FrontParams p) {
+    const int r4 = p.R / 4;
+    const int per_row = p.G > 0 ? r4 * p.G : 1;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long rows = (long long)p.N * p.T;
+    if (idx >= rows * per_row) return;
+    const long long row = idx / per_row;
+    const int sub = (int)(idx % per_row);
+    const int t = (int)(row % p.T);
+    auto xval = [&](long long rr) -> float {
+        const float zv = p.z[rr];
+        return p.s ? fmaf(zv, p.s[rr * p.sb_stride], p.b[rr * p.sb_stride]) : zv;
+    };
+    if (sub == 0 && p.x_out) p.x_out[row] = xval(row);
+    if (p.G == 0) return;
+    const int g = sub / r4, c = (sub % r4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.W; ++k) {
+        const int shift = p.W - 1 - k;
+        if (shift > t) continue;
+        const float xv = xval(row - shift);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.filt[g] + (size_t)k * p.R + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w[e], acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(p.h[g] + row * p.R + c) = acc;
+}
+
+static inline unsigned blocks_for(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
+
+}  // namespace pwv
+
+using namespace pwv;
+
+extern "C" {
+
+const char* pwv_last_error(void) { return error_buffer(); }
+int pwv_version(void) { return 100; }
+int pwv_device_cus(void) {
+    const int c = device_cus();
+    return c > 0 ? c : set_error(PWV_EHIP, "no HIP device available");
+}
+
+int pwv_causal_conv_f32(const float* x, const float* filt, float* y, int N, int T, int Cin, int Cout, int W,
+                        int dilation, pwv_stream_t stream) {
+    PWV_CHECK_ARG(x && filt && y, "pwv_causal_conv_f32: NULL pointer");
+    PWV_CHECK_ARG(N >= 0 && T >= 0 && Cin >= 1 && Cout >= 1 && W >= 1 && dilation >= 1,
+                  "pwv_causal_conv_f32: bad shape N=%d T=%d Cin=%d Cout=%d W=%d d=%d", N, T, Cin, Cout, W, dilation);
+    PWV_CHECK_ARG(x != y, "pwv_causal_conv_f32: in-place not supported");
+    const long long total = (long long)N * T * ((Cout + 3) / 4);
+    if (total == 0) return PWV_OK;
+    hipLaunchKernelGGL(causal_conv_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, filt, y,
+                       N, T, Cin, Cout, W, dilation);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int Nout, int relu,
+                   pwv_stream_t stream) {
+    PWV_CHECK_ARG(x && w && y, "pwv_linear_f32: NULL pointer");
+    PWV_CHECK_ARG(M >= 0 && K >= 8 && K % 8 == 0 && K <= 128, "pwv_linear_f32: K must be a multiple of 8 in [8,128], got %d", K);
+    PWV_CHECK_ARG(Nout >= 4 && Nout % 4 == 0, "pwv_linear_f32: Nout must be a multiple of 4, got %d", Nout);
+    if (M == 0) return PWV_OK;
+    const int kh = K / 2;   // floats per lane half, loaded as float4 chunks
+    const unsigned gx = (unsigned)((M + 127) / 128);
+    unsigned gy = (unsigned)((Nout + 127) / 128);
+    if (gy > 64) gy = 64;
+    dim3 grid(gx, gy), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (kh <= 32)
+        hipLaunchKernelGGL((linear_kernel<8>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    else if (kh <= 40)
+        hipLaunchKernelGGL((linear_kernel<10>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    else
+        hipLaunchKernelGGL((linear_kernel<16>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_upsample_repeat_f32(const float* frames, float* out, int N, int t_mel, int C, int T, int hop, int offset,
+                            pwv_stream_t stream) {
+    PWV_CHECK_ARG(frames && out, "pwv_upsample_repeat_f32: NULL pointer");
+    PWV_CHECK_ARG(N >= 0 && t_mel >= 1 && C >= 4 && C % 4 == 0 && T >= 0 && hop >= 1 && offset >= 0,
+                  "pwv_upsample_repeat_f32: bad shape (C must be a multiple of 4)");
+    PWV_CHECK_ARG(T == 0 || (T - 1 + offset) / hop < t_mel, "pwv_upsample_repeat_f32: T=%d needs more than t_mel=%d frames", T, t_mel);
+    const long long total = (long long)N * T * (C / 4);
+    if (total == 0) return PWV_OK;
+    hipLaunchKernelGGL(upsample_repeat_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, frames,
+                       out, N, t_mel, C / 4, T, hop, offset);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_crop_time_f32(const float* in, float* out, int N, int T_in, int C, int T_out, int offset, pwv_stream_t stream) {
+    PWV_CHECK_ARG(in && out, "pwv_crop_time_f32: NULL pointer");
+    PWV_CHECK_ARG(C >= 4 && C % 4 == 0 && offset >= 0 && T_out >= 0 && offset + T_out <= T_in,
+                  "pwv_crop_time_f32: bad crop (T_in=%d T_out=%d offset=%d C=%d)", T_in, T_out, offset, C);
+    const long long total = (long long)N * T_out * (C / 4);
+    if (total == 0) return PWV_OK;
+    hipLaunchKernelGGL(crop_time_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N,
+                       T_in, C / 4, T_out, offset);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, pwv_stream_t stream) {
+    PWV_CHECK_ARG(z && n >= 0, "pwv_logistic_noise_f32: bad arguments");
+    if (n == 0) return PWV_OK;
+    hipLaunchKernelGGL(logistic_noise_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, z,
+                       (long long)n, (unsigned long long)seed, (unsigned long long)offset);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_stride, float* x_out, int G,
+                      const float* const* filt, float* const* h, int N, int T, int W, int R, pwv_stream_t stream) {
+    PWV_CHECK_ARG(z, "pwv_iaf_front_f32: z is NULL");
+    PWV_CHECK_ARG((s == nullptr) == (b == nullptr), "pwv_iaf_front_f32: s and b must both be set or both NULL");
+    PWV_CHECK_ARG(G >= 0 && G <= PWV_MAX_NETS, "pwv_iaf_front_f32: G=%d out of range", G);
+    PWV_CHECK_ARG(N >= 1 && T >= 1 && W >= 1, "pwv_iaf_front_f32: bad N/T/W");
+    PWV_CHECK_ARG(G == 0 || (R >= 4 && R % 4 == 0), "pwv_iaf_front_f32: R must be a multiple of 4");
+    PWV_CHECK_ARG(G > 0 || x_out, "pwv_iaf_front_f32: nothing to do");
+    PWV_CHECK_ARG(sb_stride >= 1 || !s, "pwv_iaf_front_f32: sb_stride must be >= 1");
+    FrontParams p{};
+    p.z = z;
+    p.s = s;
+    p.b = b;
+    p.x_out = x_out;
+    p.sb_stride = sb_stride;
+    p.G = G;
+    p.N = N;
+    p.T = T;
+    p.W = W;
+    p.R = R;
+    for (int g = 0; g < G; ++g) {
+        PWV_CHECK_ARG(filt && h && filt[g] && h[g], "pwv_iaf_front_f32: NULL filter / output for net %d", g);
+        p.filt[g] = filt[g];
+        p.h[g] = h[g];
+    }
+    const long long total = (long long)N * T * (G > 0 ? (R / 4) * G : 1);
+    hipLaunchKernelGGL(iaf_front_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+}  // extern "C"

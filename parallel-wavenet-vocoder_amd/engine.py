@@ -1,0 +1,300 @@
+"""Host-side orchestration of the HIP kernels for one or two WaveNets evaluated side by side.
+
+This is plumbing: it owns no arithmetic.  It packs TF-layout weights once per variable-store
+version (pwv_pack_*), allocates the ping-pong activation buffers in HBM through torch's caching
+allocator, and enqueues the per-layer launches of libpwv_hip.so on torch's current HIP stream.
+
+Data layout in HBM (all float32, channels-last):
+  residual stream   2 x [N, T, 64] per net (ping-pong; a layer reads x[t], x[t-d] and writes out[t])
+  projection P      [N*t_mel, 128*L] per net: relu(mel@dense) @ [gc_filter‖gc_gate] + biases for
+                    all L layers at FRAME rate (hoisted: modules.py:216-228 are the same dot
+                    products for all 80 samples of a frame), columns in the kernel's order
+  net output        [N, T, Q]
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_void_p
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import HeadArgs, LayerArgs, check
+
+PRECISIONS = {'f32': _lib.PREC_F32, 'f16x3': _lib.PREC_F16X3}
+DEFAULT_PRECISION = 'f32'
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % what)
+    if not t.is_cuda:
+        raise _lib.PwvError('%s must live on the GPU (cuda device); there is no CPU path' % what)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class RepeatedCondition:
+    """Frame-rate condition + the 'repeat' upsampling rule (models.py:131-133), kept lazy:
+    sample t of the upsampled condition is ``frames[:, (t + offset) // hop, :]``.  WaveNet layers
+    project it at frame rate instead of materialising the [N, T, C] tensor."""
+
+    def __init__(self, frames: torch.Tensor, hop: int, offset: int, length: int):
+        self.frames = frames          # [N, t_mel, C]
+        self.hop, self.offset, self.length = int(hop), int(offset), int(length)
+        if (self.length - 1 + self.offset) // self.hop >= frames.shape[1]:
+            raise ValueError('length %d needs more than %d frames' % (length, frames.shape[1]))
+
+    @property
+    def shape(self):
+        return (self.frames.shape[0], self.length, self.frames.shape[2])
+
+    def materialize(self) -> torch.Tensor:
+        n, t_mel, c = self.frames.shape
+        out = torch.empty((n, self.length, c), dtype=torch.float32, device=self.frames.device)
+        check(_lib.lib().pwv_upsample_repeat_f32(_ptr(self.frames), _ptr(out), n, t_mel, c, self.length,
+                                                 self.hop, self.offset, _stream()), 'pwv_upsample_repeat_f32')
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# thin op wrappers
+# --------------------------------------------------------------------------------------------
+def causal_conv_op(value: torch.Tensor, filter_: torch.Tensor, dilation: int) -> torch.Tensor:
+    value = _require_cuda_f32(value, 'value')
+    filter_ = _require_cuda_f32(filter_, 'filter_')
+    if value.dim() != 3 or filter_.dim() != 3 or value.shape[2] != filter_.shape[1]:
+        raise ValueError('causal_conv: value [N,T,Cin] / filter [W,Cin,Cout] mismatch: %s vs %s'
+                         % (tuple(value.shape), tuple(filter_.shape)))
+    n, t, cin = value.shape
+    w, _, cout = filter_.shape
+    out = torch.empty((n, t, cout), dtype=torch.float32, device=value.device)
+    if out.numel() == 0:
+        return out
+    check(_lib.lib().pwv_causal_conv_f32(_ptr(value), _ptr(filter_), _ptr(out), n, t, cin, cout, w, int(dilation),
+                                         _stream()), 'pwv_causal_conv_f32')
+    return out
+
+
+def linear_op(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    m, k = x2d.shape
+    nout = w.shape[1]
+    y = torch.empty((m, nout), dtype=torch.float32, device=x2d.device)
+    check(_lib.lib().pwv_linear_f32(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(y), m, k, nout, int(relu), _stream()),
+          'pwv_linear_f32')
+    return y
+
+
+def crop_time_op(x: torch.Tensor, t_out: int, offset: int) -> torch.Tensor:
+    n, t_in, c = x.shape
+    out = torch.empty((n, t_out, c), dtype=torch.float32, device=x.device)
+    check(_lib.lib().pwv_crop_time_f32(_ptr(x), _ptr(out), n, t_in, c, t_out, offset, _stream()), 'pwv_crop_time_f32')
+    return out
+
+
+def logistic_noise_op(shape: Sequence[int], device, seed: int, offset: int = 0) -> torch.Tensor:
+    z = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    check(_lib.lib().pwv_logistic_noise_f32(_ptr(z), z.numel(), seed, offset, _stream()), 'pwv_logistic_noise_f32')
+    return z
+
+
+def iaf_affine_op(z: torch.Tensor, s: torch.Tensor, b: torch.Tensor, sb_stride: int = 1) -> torch.Tensor:
+    """out = z*s + b (modules.py:59); s/b may be strided views (shared net: stride 2)."""
+    n, t = z.shape[0], z.shape[1]
+    out = torch.empty_like(z)
+    check(_lib.lib().pwv_iaf_front_f32(_ptr(z), s.data_ptr(), b.data_ptr(), sb_stride, _ptr(out), 0, None, None,
+                                       n, t, 1, 4, _stream()), 'pwv_iaf_front_f32')
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# per-net plan: packed weights resident in HBM
+# --------------------------------------------------------------------------------------------
+class NetPlan:
+    def __init__(self, net, cond_mode: str, precision: int):
+        """cond_mode: 'none' | 'frames' (hoisted projection) | 'samples' (per-sample cond GEMM)."""
+        lib = _lib.lib()
+        self.cond_mode = cond_mode
+        self.precision = precision
+        L = len(net.dilations)
+        dev = net.device()
+        use_skip = bool(net.use_skip_connection)
+        cond_c = net.condition_channels if cond_mode == 'samples' else 0
+        self.with_skip = use_skip
+        self.layer_floats = lib.pwv_layer_packed_floats(int(use_skip), cond_c)
+        self.packed_layers = torch.empty((L, self.layer_floats), dtype=torch.float32, device=dev)
+        s = _stream()
+        colmap = torch.tensor(_lib.proj_column_map(), dtype=torch.long, device=dev)
+        proj_w, proj_b = [], []
+        for j in range(L):
+            v = net.layer_variables(j, with_cond=cond_mode != 'none')
+            check(lib.pwv_pack_layer_f32(_ptr(v['filter']), _ptr(v['gate']), _ptr(v['dense']), _ptr(v.get('dense_bias')),
+                                         _ptr(v['skip']) if use_skip else None,
+                                         _ptr(v.get('skip_bias')) if use_skip else None,
+                                         _ptr(v.get('gc_filter')) if cond_c else None,
+                                         _ptr(v.get('gc_gate')) if cond_c else None,
+                                         int(use_skip), cond_c, precision, _ptr(self.packed_layers[j]), s),
+                  'pwv_pack_layer_f32')
+            if net.use_biases:
+                b = torch.cat([v['filter_bias'], v['gate_bias']])
+            else:
+                b = torch.zeros(128, dtype=torch.float32, device=dev)
+            proj_b.append(b[colmap])
+            if cond_mode == 'frames':
+                wfg = torch.cat([v['gc_filter'][0], v['gc_gate'][0]], dim=1)      # [C, 128]
+                proj_w.append(wfg[:, colmap])
+        self.proj_b = torch.cat(proj_b).contiguous()                              # [128*L]
+        self.proj_w = torch.cat(proj_w, dim=1).contiguous() if proj_w else None   # [C, 128*L]
+        hv = net.head_variables()
+        last = net.layer_variables(L - 1, with_cond=False)
+        self.head_floats = lib.pwv_head_packed_floats(net.out_channels)
+        self.packed_head = torch.empty((self.head_floats,), dtype=torch.float32, device=dev)
+        check(lib.pwv_pack_head_f32(None if use_skip else _ptr(last['skip']),
+                                    None if use_skip else _ptr(last.get('skip_bias')),
+                                    _ptr(hv['postprocess1']), _ptr(hv.get('postprocess1_bias')),
+                                    _ptr(hv['postprocess2']), _ptr(hv.get('postprocess2_bias')),
+                                    net.out_channels, precision, _ptr(self.packed_head), s), 'pwv_pack_head_f32')
+        self.causal_filter = net.causal_filter()
+        self.n_layers = L
+
+
+_plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
+
+
+def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
+    key = (id(net.store), net.full_scope, cond_mode, precision)
+    hit = _plan_cache.get(key)
+    if hit is not None and hit[0] == net.store.version:
+        return hit[1]
+    plan = NetPlan(net, cond_mode, precision)
+    _plan_cache[key] = (net.store.version, plan)   # read AFTER planning: creating variables bumps it
+    return plan
+
+
+def clear_plan_cache() -> None:
+    _plan_cache.clear()
+
+
+def _same_structure(a, b) -> bool:
+    return (list(a.dilations) == list(b.dilations) and a.use_skip_connection == b.use_skip_connection
+            and a.in_channels == b.in_channels and a.out_channels == b.out_channels
+            and a.condition_channels == b.condition_channels and a.filter_width == b.filter_width)
+
+
+def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,
+             max_workgroups: int = 0) -> List[torch.Tensor]:
+    """Evaluate 1 or 2 structurally identical fused-capable WaveNets on the same input/condition.
+    Returns one [N, T, Q] tensor per net."""
+    lib = _lib.lib()
+    prec = PRECISIONS[precision or DEFAULT_PRECISION]
+    x = _require_cuda_f32(x, 'input_batch')
+    if x.dim() != 3:
+        raise ValueError('input_batch must be [N, T, C], got %s' % (tuple(x.shape),))
+    n, t, qin = x.shape
+    G = len(nets)
+    assert 1 <= G <= _lib.PWV_MAX_NETS
+    net0 = nets[0]
+    for other in nets[1:]:
+        assert _same_structure(net0, other)
+    if qin != net0.in_channels:
+        raise ValueError('input has %d channels, net expects %d' % (qin, net0.in_channels))
+    if n * t == 0:
+        return [torch.empty((n, t, net0.out_channels), dtype=torch.float32, device=x.device) for _ in nets]
+    dev = x.device
+    s = _stream()
+
+    # ---- conditioning mode ------------------------------------------------------------------
+    cond_t = None
+    hop = offset = frames_per_utt = 0
+    if cond is None:
+        mode = 'none'
+    elif isinstance(cond, RepeatedCondition):
+        mode = 'frames'
+        if cond.length != t or cond.frames.shape[0] != n:
+            raise ValueError('condition %s does not match input %s' % (cond.shape, tuple(x.shape)))
+        if cond.frames.shape[2] != net0.condition_channels:
+            raise ValueError('condition has %d channels, net expects %d' % (cond.frames.shape[2], net0.condition_channels))
+        hop, offset, frames_per_utt = cond.hop, cond.offset, cond.frames.shape[1]
+    else:
+        mode = 'samples'
+        cond_t = _require_cuda_f32(cond, 'condition_batch')
+        if tuple(cond_t.shape) != (n, t, net0.condition_channels):
+            raise ValueError('condition_batch %s does not match input %s / %d channels'
+                             % (tuple(cond_t.shape), tuple(x.shape), net0.condition_channels))
+    plans = [get_plan(net, mode, prec) for net in nets]
+    L = plans[0].n_layers
+
+    # ---- frame-rate projection P (or bias-only row) -------------------------------------------
+    if mode == 'frames':
+        f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames_per_utt, -1)
+        projs = [linear_op(f2d, p.proj_w, p.proj_b, relu=False) for p in plans]
+    else:
+        projs = [p.proj_b.reshape(1, -1) for p in plans]
+    row_stride = 128 * L
+
+    # ---- causal layer (modules.py:174-183) ----------------------------------------------------
+    R = net0.residual_channels
+    bufs = [[torch.empty((n, t, R), dtype=torch.float32, device=dev) for _ in range(2)] for _ in nets]
+    if qin == 1:
+        filt = (c_void_p * G)(*[p.causal_filter.data_ptr() for p in plans])
+        hout = (c_void_p * G)(*[b[0].data_ptr() for b in bufs])
+        check(lib.pwv_iaf_front_f32(_ptr(x), None, None, 1, None, G, filt, hout, n, t, net0.filter_width, R, s),
+              'pwv_iaf_front_f32')
+    else:
+        for g, p in enumerate(plans):
+            check(lib.pwv_causal_conv_f32(_ptr(x), _ptr(p.causal_filter), _ptr(bufs[g][0]), n, t, qin, R,
+                                          net0.filter_width, 1, s), 'pwv_causal_conv_f32')
+
+    use_skip = bool(net0.use_skip_connection)
+    skips = [torch.empty((n, t, net0.skip_channels), dtype=torch.float32, device=dev) for _ in nets] if use_skip else None
+
+    # ---- dilated stack ----------------------------------------------------------------------------
+    a = LayerArgs()
+    a.G = G
+    a.proj_row_stride = row_stride
+    a.cond = _ptr(cond_t)
+    a.cond_channels = net0.condition_channels if mode == 'samples' else 0
+    a.N, a.T = n, t
+    a.cond_hop, a.cond_offset, a.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
+    a.precision = prec
+    a.max_workgroups = max_workgroups
+    cur = 0
+    for j, d in enumerate(net0.dilations):
+        last = j == L - 1
+        for g in range(G):
+            a.x_in[g] = bufs[g][cur].data_ptr()
+            a.x_out[g] = bufs[g][cur ^ 1].data_ptr()
+            a.packed[g] = plans[g].packed_layers[j].data_ptr()
+            a.proj[g] = projs[g].data_ptr() + 4 * 128 * j
+            a.skip[g] = skips[g].data_ptr() if use_skip else None
+        a.skip_init = 1 if j == 0 else 0
+        a.dilation = int(d)
+        a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
+        check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s), 'pwv_wavenet_layer_f32')
+        cur ^= 1
+
+    # ---- post-processing head -----------------------------------------------------------------------
+    Q = net0.out_channels
+    outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
+    h = HeadArgs()
+    h.G = G
+    h.N, h.T, h.Q = n, t, Q
+    h.in_mode = _lib.HEAD_IN_SKIPSUM if use_skip else _lib.HEAD_IN_GATED
+    h.precision = prec
+    h.max_workgroups = max_workgroups
+    for g in range(G):
+        h.in_[g] = skips[g].data_ptr() if use_skip else bufs[g][cur].data_ptr()
+        h.packed[g] = plans[g].packed_head.data_ptr()
+        h.out[g] = outs[g].data_ptr()
+    check(lib.pwv_wavenet_head_f32(ctypes.byref(h), s), 'pwv_wavenet_head_f32')
+    return outs

@@ -1,0 +1,132 @@
+"""IAFVocoder: the 4-flow IAF-WaveNet student, generation (forward) path only.
+
+Counterpart of /root/reference/models.py:16-141 with the same constructor / call signature
+(`IAFVocoder(batch_size, length)`, `model(wav, melspec, is_training, name='iaf_vocoder')`,
+`_upsample_cond(melspec, is_training, strides)`), reading the same global `hparam`.
+Training hooks (tensorpack ModelDesc, losses, optimizer: models.py:80-103) are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import engine
+from .engine import RepeatedCondition
+from .hparam import hparam as hp
+from .modules import LinearIAFLayer, SharedIAFLayer, WaveNet, normalize
+from .variables import VariableStore, get_default_store, get_variable, variable_scope
+
+
+class IAFVocoder(object):
+
+    def __init__(self, batch_size, length, store: Optional[VariableStore] = None, precision: Optional[str] = None):
+        self.batch_size = batch_size
+        self.t_mel = 1 + length // hp.signal.hop_length          # models.py:20
+        self.length = length
+        self.store = store
+        self.precision = precision
+        self.ema = None
+        self.noise_seed = 1
+
+    # -- network (models.py:23-78) -------------------------------------------------------------------
+    def __call__(self, wav, melspec, is_training=False, name='iaf_vocoder', z=None):
+        """wav is unused by the forward (as in the reference); melspec [N, t_mel, n_mels] on the
+        GPU.  ``z`` (optional, [N, length, 1]) replaces the logistic noise sampled at
+        models.py:32-33 so results are reproducible against the oracle."""
+        store = self.store or get_default_store()
+        melspec = engine._require_cuda_f32(melspec, 'melspec')
+        if melspec.dim() != 3 or melspec.shape[1] != self.t_mel or melspec.shape[2] != hp.signal.n_mels:
+            raise ValueError('melspec must be [N, %d, %d], got %s' % (self.t_mel, hp.signal.n_mels, tuple(melspec.shape)))
+        n = melspec.shape[0]
+        shared = bool(hp.model.get('shared_nets', False))
+        with variable_scope(name):
+            with variable_scope('cond'):
+                condition = self._condition(melspec, is_training, strides=[4, 4, 5], store=store)   # (n, t, h)
+                if hp.model.normalize_cond and condition is not None:
+                    if isinstance(condition, RepeatedCondition):
+                        condition = condition.materialize()
+                    with variable_scope('normalize'):
+                        condition = normalize(condition, is_training, hp.model.normalize_cond, store=store)
+
+            if z is None:   # Logistic(0,1) noise, models.py:32-33
+                input = engine.logistic_noise_op((n, self.length, 1), melspec.device, seed=self.noise_seed)
+            else:
+                input = engine._require_cuda_f32(z, 'z')
+                if tuple(input.shape) != (n, self.length, 1):
+                    raise ValueError('z must be [%d, %d, 1], got %s' % (n, self.length, tuple(input.shape)))
+            for i in range(hp.model.n_iaf):
+                with variable_scope('iaf{}'.format(i)):
+                    kwargs = dict(
+                        batch_size=self.batch_size,
+                        dilations=hp.model.dilations[i],
+                        filter_width=hp.model.filter_width,
+                        residual_channels=hp.model.residual_channels,
+                        dilation_channels=hp.model.dilation_channels,
+                        skip_channels=hp.model.skip_channels,
+                        use_biases=hp.model.use_biases,
+                        condition_channels=hp.model.condition_channels,
+                        use_skip_connection=hp.model.use_skip_connection,
+                        is_training=is_training,
+                        normalize=hp.model.normalize_wavenet,
+                        store=store, precision=self.precision)
+                    if shared:   # build extension: BASELINE.json configs[1]
+                        net = WaveNet(quantization_channels=2, input_channels=1, name='shared', **kwargs)
+                        iaf = SharedIAFLayer(batch_size=hp.train.batch_size, net=net)
+                    else:
+                        # quantization_channels=1: the output is a real value, models.py:42,57
+                        scaler = WaveNet(quantization_channels=1, name='scalar', **kwargs)
+                        shifter = WaveNet(quantization_channels=1, name='shifter', **kwargs)
+                        iaf = LinearIAFLayer(batch_size=hp.train.batch_size, scaler=scaler, shifter=shifter)
+                    input = iaf(input, condition)  # (n, t, h)
+
+                # normalization (identity at the default hparams), models.py:70
+                input = normalize(input, is_training, hp.model.normalize, name='normalize{}'.format(i), store=store)
+        return input
+
+    # -- condition upsampling (models.py:105-136) ----------------------------------------------------
+    def _condition(self, melspec, is_training, strides, store):
+        """The condition in the form the kernels want: a lazy RepeatedCondition for 'repeat'
+        (projected at frame rate inside the nets), a materialised [N, T, C] tensor for
+        'transposed_conv', None otherwise."""
+        hop = hp.signal.hop_length
+        assert (np.prod(np.array(strides)) == hop)                              # models.py:106
+        if self.length % hop != 0:
+            raise ValueError('length (%d) must be a multiple of hop_length (%d): the crop at models.py:124,133 '
+                             'yields (t_mel-1)*hop samples' % (self.length, hop))
+        method = hp.model.cond_upsample_method
+        n, t_mel, n_mels = melspec.shape
+        C = hp.model.condition_channels
+        if method == 'transposed_conv':
+            cond = melspec.reshape(n * t_mel, n_mels)
+            length = t_mel
+            input_channels = n_mels
+            for i, stride in enumerate(strides):
+                w = get_variable('transposed_conv_{}_weights'.format(i), (1, stride, C, input_channels), store=store)
+                # kernel width == stride: out[t*s + j, co] = sum_ci in[t, ci] * w[0, j, co, ci]  (a GEMM)
+                wmat = w[0].permute(2, 0, 1).reshape(input_channels, stride * C).contiguous()
+                cond = engine.linear_op(cond, wmat, None, relu=True)            # models.py:118-120
+                input_channels = C
+                length *= stride
+                cond = cond.reshape(n * length, C)
+                if hp.model.normalize_cond:
+                    cond = normalize(cond.reshape(n, length, C), is_training, hp.model.normalize_cond,
+                                     name='normalize_transposed_conv_{}'.format(i), store=store).reshape(n * length, C)
+            cond = cond.reshape(n, length, C)
+            return engine.crop_time_op(cond, length - hop, hop // 2)            # models.py:124
+        elif method == 'repeat':
+            w = get_variable('dense', [1, n_mels, C], store=store)
+            frames = engine.linear_op(melspec.reshape(n * t_mel, n_mels), w[0], None, relu=True)   # models.py:128-130
+            return RepeatedCondition(frames.reshape(n, t_mel, C), hop, hop // 2, self.length)      # models.py:131-133
+        return None
+
+    def _upsample_cond(self, melspec, is_training, strides):
+        """Reference signature (models.py:105): returns the upsampled condition [N, T, C] tensor."""
+        melspec = engine._require_cuda_f32(melspec, 'melspec')
+        with variable_scope('iaf_vocoder'):
+            with variable_scope('cond'):
+                cond = self._condition(melspec, is_training, strides, self.store or get_default_store())
+        if isinstance(cond, RepeatedCondition):
+            cond = cond.materialize()
+        return cond

@@ -1,0 +1,140 @@
+"""A small stand-in for TensorFlow's variable store / variable scopes.
+
+The reference builds its weights with ``tf.get_variable`` inside nested
+``tf.variable_scope``s (modules.py:131-165,179,210-248; models.py:24-35,114-115,128) and
+restores them by *name* from a checkpoint, preferring the EMA shadow
+``<name>/ExponentialMovingAverage`` (generate.py:55-66, models.py:72-76).  This module keeps
+those semantics -- same names, same TF layouts ``[width, Cin, Cout]``, random (glorot-uniform)
+initialisation when no checkpoint is found -- on torch tensors resident in HBM.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+import zlib
+from typing import Dict, Iterable, Optional, Sequence
+
+import numpy as np
+import torch
+
+EMA_SUFFIX = '/ExponentialMovingAverage'
+
+
+class VariableStore:
+    def __init__(self, device: Optional[torch.device] = None, seed: int = 2):
+        self.device = torch.device(device) if device is not None else None
+        self.seed = seed
+        self.vars: Dict[str, torch.Tensor] = {}
+        self.version = 0            # bumped on every change; packed-weight caches key on it
+
+    # -- tf.get_variable -------------------------------------------------------------------
+    def get_variable(self, name: str, shape: Sequence[int], initializer: Optional[str] = None) -> torch.Tensor:
+        shape = tuple(int(s) for s in shape)
+        if name in self.vars:
+            v = self.vars[name]
+            if tuple(v.shape) != shape:
+                raise ValueError('variable %s exists with shape %s, requested %s' % (name, tuple(v.shape), shape))
+            return v
+        if self.device is None:
+            raise RuntimeError('VariableStore has no device; create it with device=... before building a model')
+        gen = torch.Generator().manual_seed((self.seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+        if initializer == 'zeros':
+            v = torch.zeros(shape)
+        elif initializer == 'ones':
+            v = torch.ones(shape)
+        else:   # TF's default for get_variable without an initializer: glorot_uniform
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            fan_in = rf * (shape[-2] if len(shape) > 1 else shape[0])
+            fan_out = rf * shape[-1]
+            limit = math.sqrt(6.0 / (fan_in + fan_out))
+            v = (torch.rand(shape, generator=gen) * 2 - 1) * limit
+        v = v.to(dtype=torch.float32, device=self.device).contiguous()
+        self.vars[name] = v
+        self.version += 1
+        return v
+
+    # -- checkpoints -------------------------------------------------------------------------
+    def assign(self, name: str, value) -> None:
+        t = torch.as_tensor(np.asarray(value), dtype=torch.float32)
+        if name in self.vars and tuple(self.vars[name].shape) != tuple(t.shape):
+            raise ValueError('shape mismatch for %s: %s vs %s' % (name, tuple(self.vars[name].shape), tuple(t.shape)))
+        self.vars[name] = t.to(self.device).contiguous()
+        self.version += 1
+
+    def load_dict(self, weights: Dict[str, np.ndarray], use_ema: bool = False, strict: bool = False) -> int:
+        """Restore by TF variable name.  With ``use_ema`` a shadow ``<name>/ExponentialMovingAverage``
+        wins over the raw variable (generate.py:59-63).  Returns the number of variables set."""
+        loaded = 0
+        names = set(k[:-len(EMA_SUFFIX)] if k.endswith(EMA_SUFFIX) else k for k in weights)
+        for name in sorted(names):
+            key = name + EMA_SUFFIX if (use_ema and name + EMA_SUFFIX in weights) else name
+            if key not in weights:
+                if strict:
+                    raise KeyError(name)
+                continue
+            self.assign(name.split(':')[0], weights[key])
+            loaded += 1
+        return loaded
+
+    def load_npz(self, path: str, use_ema: bool = False) -> int:
+        with np.load(path) as z:
+            return self.load_dict({k: z[k] for k in z.files}, use_ema=use_ema)
+
+    def save_npz(self, path: str) -> None:
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.vars.items()})
+
+    def numpy(self) -> Dict[str, np.ndarray]:
+        return {k: v.detach().cpu().numpy() for k, v in self.vars.items()}
+
+    def trainable_variables(self, scope: str = '') -> Iterable[str]:
+        return [k for k in self.vars if k.startswith(scope)]
+
+
+_default_store: Optional[VariableStore] = None
+_scope_stack = []
+
+
+def get_default_store() -> VariableStore:
+    global _default_store
+    if _default_store is None:
+        dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+        _default_store = VariableStore(device=dev)
+    return _default_store
+
+
+def set_default_store(store: Optional[VariableStore]) -> None:
+    global _default_store
+    _default_store = store
+
+
+def reset_default_store(device=None, seed: int = 2) -> VariableStore:
+    """The analogue of starting a fresh ``tf.Graph()`` (generate.py:25)."""
+    global _default_store
+    if device is None and torch.cuda.is_available():
+        device = torch.device('cuda', torch.cuda.current_device())
+    _default_store = VariableStore(device=device, seed=seed)
+    return _default_store
+
+
+@contextlib.contextmanager
+def variable_scope(name: str):
+    """tf.variable_scope: names created inside get the prefix ``<name>/``."""
+    _scope_stack.append(name)
+    try:
+        yield
+    finally:
+        _scope_stack.pop()
+
+
+def current_scope() -> str:
+    return '/'.join(s for s in _scope_stack if s)
+
+
+def scoped(name: str) -> str:
+    pre = current_scope()
+    return pre + '/' + name if pre else name
+
+
+def get_variable(name: str, shape: Sequence[int], initializer: Optional[str] = None,
+                 store: Optional[VariableStore] = None) -> torch.Tensor:
+    return (store or get_default_store()).get_variable(scoped(name), shape, initializer)

@@ -1,0 +1,171 @@
+"""-m gpu: parity of the HIP path (through the C ABI, via the reference-shaped host API) against
+the CPU oracle on the same seeded inputs.  fp32 tolerance: max|y - y_fp64| <= 2e-5 (util.TOL_F32)."""
+import numpy as np
+import pytest
+
+from oracle import iaf_oracle as O
+from tests.util import TOL_F32, run_vocoder_hip, set_hparams, small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+@pytest.mark.parametrize('N,T,Cin,Cout,W,d', [
+    (1, 10, 1, 64, 2, 1), (3, 33, 5, 7, 2, 3), (3, 37, 5, 7, 3, 4), (1, 64, 64, 64, 2, 8),
+    (2, 10, 4, 4, 2, 512), (3, 37, 8, 12, 3, 16), (2, 100, 80, 64, 1, 1), (1, 1, 3, 3, 2, 1),
+])
+def test_causal_conv(gpu, N, T, Cin, Cout, W, d):
+    from pwv_amd.modules import causal_conv
+    rng = np.random.RandomState(0)
+    x = rng.randn(N, T, Cin).astype(np.float32)
+    f = rng.randn(W, Cin, Cout).astype(np.float32)
+    want = O.causal_conv_literal(x.astype(np.float64), f.astype(np.float64), d)
+    got = causal_conv(_t(x, gpu), _t(f, gpu), d).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_causal_conv_empty(gpu):
+    from pwv_amd.modules import causal_conv
+    import torch
+    y = causal_conv(torch.zeros((2, 0, 4), device=gpu), torch.zeros((2, 4, 6), device=gpu), 2)
+    assert tuple(y.shape) == (2, 0, 6)
+
+
+@pytest.mark.parametrize('M,K,Nout,relu,bias', [(201, 80, 80, True, False), (50, 80, 400, True, False),
+                                                (333, 80, 1280, False, True), (7, 64, 36, False, True),
+                                                (129, 128, 132, True, True)])
+def test_linear(gpu, M, K, Nout, relu, bias):
+    from pwv_amd import engine
+    rng = np.random.RandomState(1)
+    x = rng.randn(M, K).astype(np.float32)
+    w = (rng.randn(K, Nout) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(Nout).astype(np.float32) if bias else None
+    want = x.astype(np.float64) @ w.astype(np.float64) + (b.astype(np.float64) if bias else 0)
+    if relu:
+        want = np.maximum(want, 0)
+    got = engine.linear_op(_t(x, gpu), _t(w, gpu), _t(b, gpu) if bias else None, relu).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5
+
+
+def _wavenet_case(gpu, cond_mode, use_skip, use_biases, q_out, T=300, N=2, dil=(1, 2, 4, 8, 16)):
+    import torch
+    from pwv_amd.engine import RepeatedCondition
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore, variable_scope
+    rng = np.random.RandomState(3)
+    cfg = O.ModelConfig(dilations=[list(dil)], n_iaf=1, use_skip_connection=use_skip, use_biases=use_biases,
+                        cond_upsample_method='repeat' if cond_mode != 'none' else 'none',
+                        shared_nets=(q_out == 2))
+    weights = O.init_weights(cfg, seed=5)
+    net_name = 'shared' if q_out == 2 else 'scalar'
+    scope = 'iaf_vocoder/iaf0/' + net_name
+    x = rng.randn(N, T, 1).astype(np.float32)
+    hop = 80
+    cond_np = None
+    cond_dev = None
+    if cond_mode != 'none':
+        assert T % hop == 0
+        frames = np.maximum(rng.randn(N, T // hop + 1, 80), 0).astype(np.float32)
+        cond_np = np.repeat(frames, hop, axis=1)[:, hop // 2: -(hop // 2), :]
+        if cond_mode == 'frames':
+            cond_dev = RepeatedCondition(_t(frames, gpu), hop, hop // 2, T)
+        else:
+            cond_dev = _t(cond_np, gpu)
+    want = O.wavenet_forward(weights, scope, x, cond_np, dilations=list(dil), use_biases=use_biases,
+                             use_skip_connection=use_skip)
+    store = VariableStore(device=gpu)
+    store.load_dict(weights)
+    with variable_scope('iaf_vocoder'), variable_scope('iaf0'):
+        net = WaveNet(batch_size=N, dilations=list(dil), filter_width=2, residual_channels=64, dilation_channels=64,
+                      skip_channels=128, quantization_channels=q_out, input_channels=1, use_biases=use_biases,
+                      condition_channels=80 if cond_mode != 'none' else None, use_skip_connection=use_skip,
+                      name=net_name, store=store)
+    assert net.fused_supported(cond_dev)
+    got = net(_t(x, gpu), cond_dev)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert got.shape == want.shape
+    err = np.abs(got - want).max()
+    assert err <= TOL_F32, err
+
+
+@pytest.mark.parametrize('cond_mode', ['frames', 'none', 'samples'])
+@pytest.mark.parametrize('use_skip', [False, True])
+def test_wavenet_fused(gpu, cond_mode, use_skip):
+    _wavenet_case(gpu, cond_mode, use_skip, use_biases=True, q_out=1, T=320)
+
+
+def test_wavenet_no_biases_q2(gpu):
+    _wavenet_case(gpu, 'frames', False, use_biases=False, q_out=2, T=240)
+
+
+def test_wavenet_ragged_tail_and_big_dilation(gpu):
+    # T not a multiple of the 128-row tile, dilation larger than a tile and larger than T/2
+    _wavenet_case(gpu, 'none', False, True, 1, T=333, N=3, dil=(1, 512, 2, 256, 128))
+
+
+@pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
+def test_vocoder_small(gpu, method):
+    cfg = small_cfg(cond_upsample_method=method)
+    weights = O.init_weights(cfg, seed=2)
+    mel, z = O.synthetic_inputs(2, 480, cfg)
+    want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    err = np.abs(got - want).max()
+    assert got.shape == want.shape and err <= TOL_F32, err
+
+
+def test_vocoder_default_model_1s(gpu):
+    """The reference-default model (4 flows, 8 nets, 120 layers) on 0.5 s of synthetic mel."""
+    cfg = O.ModelConfig()
+    weights = O.init_weights(cfg, seed=2)
+    mel, z = O.synthetic_inputs(1, 8000, cfg)
+    want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    err = np.abs(got - want).max()
+    assert err <= TOL_F32, err
+
+
+def test_vocoder_shared_nets(gpu):
+    cfg = small_cfg(shared_nets=True)
+    weights = O.init_weights(cfg, seed=2)
+    mel, z = O.synthetic_inputs(2, 400, cfg)
+    want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    assert np.abs(got - want).max() <= TOL_F32
+
+
+def test_upsample_cond_api(gpu):
+    """IAFVocoder._upsample_cond returns the materialised [N, T, C] condition (models.py:105-136)."""
+    import torch
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    for method in ('repeat', 'transposed_conv'):
+        cfg = small_cfg(cond_upsample_method=method)
+        weights = O.init_weights(cfg, seed=4)
+        mel, _ = O.synthetic_inputs(2, 320, cfg)
+        set_hparams(cfg)
+        store = VariableStore(device=gpu)
+        store.load_dict(weights)
+        model = IAFVocoder(batch_size=2, length=320, store=store)
+        got = model._upsample_cond(torch.from_numpy(mel).to(gpu), is_training=False, strides=[4, 4, 5]).cpu().numpy()
+        if method == 'repeat':
+            want = O.upsample_cond_repeat(weights, mel, 80)
+        else:
+            want = O.upsample_cond_transposed(weights, mel, 80, (4, 4, 5))
+        assert got.shape == want.shape == (2, 320, 80)
+        assert np.abs(got - want).max() <= 1e-5
+
+
+def test_logistic_noise(gpu):
+    from pwv_amd import engine
+    z = engine.logistic_noise_op((4, 50000, 1), gpu, seed=7).cpu().numpy().ravel()
+    z2 = engine.logistic_noise_op((4, 50000, 1), gpu, seed=7).cpu().numpy().ravel()
+    assert np.array_equal(z, z2)                       # counter-based: reproducible
+    assert np.isfinite(z).all()
+    assert abs(z.mean()) < 0.02 and abs(z.var() - np.pi ** 2 / 3) < 0.1   # Logistic(0,1)

@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (oracle = checker, HIP path = thing under test)."""
+import numpy as np
+
+from oracle import iaf_oracle as O
+
+# fp32 parity bar (SURVEY.md section 8c / BASELINE.md section 4): max |y - y_fp64| on O(1) outputs
+TOL_F32 = 2e-5
+
+
+def set_hparams(cfg: O.ModelConfig, length=None, batch=None):
+    """Point the global hparam singleton at ``cfg`` (what hp.set_hparam_yaml(case) would do)."""
+    from pwv_amd.hparam import hparam as hp
+    hp.set_hparam_yaml('default')
+    m = hp.model
+    m.dilations = [list(d) for d in cfg.dilations]
+    m.filter_width = cfg.filter_width
+    m.residual_channels = cfg.residual_channels
+    m.dilation_channels = cfg.dilation_channels
+    m.skip_channels = cfg.skip_channels
+    m.condition_channels = cfg.condition_channels
+    m.use_biases = cfg.use_biases
+    m.use_skip_connection = cfg.use_skip_connection
+    m.n_iaf = cfg.n_iaf
+    m.normalize = cfg.normalize
+    m.normalize_cond = cfg.normalize_cond
+    m.normalize_wavenet = cfg.normalize_wavenet
+    m.cond_upsample_method = cfg.cond_upsample_method
+    m.shared_nets = cfg.shared_nets
+    hp.signal.n_mels = cfg.n_mels
+    hp.signal.hop_length = cfg.hop_length
+    if length is not None:
+        hp.generate.length = length
+    if batch is not None:
+        hp.generate.batch_size = batch
+    return hp
+
+
+def run_vocoder_hip(cfg, weights, mel, z, device, precision=None):
+    """The HIP path through the reference-shaped host API: IAFVocoder(batch, length)(wav, mel, ...)."""
+    import torch
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    set_hparams(cfg)
+    store = VariableStore(device=device)
+    store.load_dict(weights)
+    n, length = z.shape[0], z.shape[1]
+    model = IAFVocoder(batch_size=n, length=length, store=store, precision=precision)
+    out = model(None, torch.from_numpy(mel).to(device), is_training=False, z=torch.from_numpy(z).to(device))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def small_cfg(**kw):
+    base = dict(dilations=[[1, 2, 4], [1, 2, 4, 8]], n_iaf=2)
+    base.update(kw)
+    return O.ModelConfig(**base)
