@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the IAF-WaveNet student generation path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full forward of the reference-default model (hparams/default.yaml as
+models.py:36-65 builds it: 4 IAF flows, separate scalar + shifter WaveNets = 8 nets, 120
+dilated layers, 'repeat' conditioning) on one batch of synthetic input: mel already in HBM
+-> logistic noise sampled on the device -> waveform in HBM, weights resident.  Workload
+("C3"): 1 utterance x 160000 samples (10 s @ 16 kHz, 2001 mel frames x 80
+mels, hop 80) per GPU; utterances shard across GPUs with no data-path collective (weak scaling).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      -- the dominant kernel (fused gated-residual layer, G=2 nets per launch): its
+                   algorithmic FLOPs per launch / its average duration measured with HIP events on
+                   the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s); the HBM view
+                   (algorithmic bytes vs 8 TB/s) is reported beside it as roofline_hbm
+  cpu_baseline  -- the oracle's torch-CPU fp32 port of the same model timed on this host's cores
+                   on a bounded sample (rank 0, N=1 only); a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# algorithmic work of ONE net-layer on ONE sample (hoisted conditioning):
+# 2*(W*R*2D + D*R) FLOP = 2*(2*64*128 + 64*64); residual stream read once + written once.
+LAYER_FLOP_PER_SAMPLE = 2 * (2 * 64 * 128 + 64 * 64)      # 40960
+LAYER_BYTES_PER_SAMPLE = 2 * 64 * 4                       # 512
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--case', default='bench/c3', help='hparams case (bench/c1..c5, default, test/tran ...)')
+    ap.add_argument('--length', type=int, default=0, help='override samples per utterance')
+    ap.add_argument('--utts', type=int, default=0, help='override utterances per GPU')
+    ap.add_argument('--precision', default='f32')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(case_cfg, target_s):
+    """Oracle port (torch-CPU fp32 restatement of modules.py:11-259 / models.py:23-136) timed on
+    the host cores on a bounded sample of the same model."""
+    import torch
+    from oracle import iaf_oracle as O
+    from oracle.torch_cpu import iaf_vocoder_forward_torch
+    cores = torch.get_num_threads()
+    w = O.init_weights(case_cfg, seed=2)
+    hop = case_cfg.hop_length
+    probe = 50 * hop
+    mel, z = O.synthetic_inputs(1, probe, case_cfg)
+    iaf_vocoder_forward_torch(w, mel, z, case_cfg)               # warm-up (oneDNN primitive caches)
+    t0 = time.perf_counter()
+    iaf_vocoder_forward_torch(w, mel, z, case_cfg)
+    rate = probe / (time.perf_counter() - t0)
+    length = int(min(160000, max(probe, rate * target_s)) // hop * hop)
+    mel, z = O.synthetic_inputs(1, length, case_cfg)
+    t0 = time.perf_counter()
+    iaf_vocoder_forward_torch(w, mel, z, case_cfg)
+    dt = time.perf_counter() - t0
+    return {'value': length / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': 'same model, 1 utterance x %d samples (%.1f s CPU), torch-CPU fp32 restatement (oracle/torch_cpu.py), '
+                      '%d threads' % (length, dt, cores)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback exists in the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)       # RCCL over xGMI
+    n_gpus = world
+
+    from oracle.iaf_oracle import ModelConfig
+    from pwv_amd import _lib, engine
+    from pwv_amd.hparam import hparam as hp
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    _lib.build_library()
+
+    hp.set_hparam_yaml(args.case)
+    length = args.length or hp.generate.length
+    utts = args.utts or hp.generate.batch_size
+    if args.case == 'bench/c4' and not args.utts:
+        utts = max(1, hp.generate.batch_size // 8)       # 64 utterances over 8 GPUs: 8 per GPU
+    hop, n_mels = hp.signal.hop_length, hp.signal.n_mels
+    t_mel = 1 + length // hop
+
+    # synthetic, seeded per rank: mel ~ U(-1,1); random-init weights (glorot + N(0,0.1) biases) so bias paths run
+    store = VariableStore(device=dev, seed=2)
+    model = IAFVocoder(batch_size=utts, length=length, store=store, precision=args.precision)
+    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    mel = (torch.rand((utts, t_mel, n_mels), generator=g) * 2 - 1).to(dev)
+    model.noise_seed = 1 + rank
+    out = model(None, mel, is_training=False)            # creates + packs the weights
+    for name in list(store.vars):
+        if store.vars[name].dim() == 1:
+            store.vars[name].normal_(0, 0.1, generator=None)
+    store.version += 1
+    engine.clear_plan_cache()
+
+    def step():
+        return model(None, mel, is_training=False)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all(), 'non-finite output'
+
+    # ---- live kernel timing of the dominant kernel (HIP events on the launch stream) -------------------
+    engine.EVENT_LOG = []
+    for _ in range(max(1, min(args.steps, 5))):
+        step()
+    torch.cuda.synchronize()
+    log, engine.EVENT_LOG = engine.EVENT_LOG, None
+    res_ms = [e0.elapsed_time(e1) for tag, e0, e1 in log if tag == 'layer_residual']
+    layer_ms = float(np.mean(res_ms))
+    rows = utts * length
+    nets_per_launch = 1 if bool(hp.model.get('shared_nets', False)) else 2
+    flop_per_launch = rows * nets_per_launch * LAYER_FLOP_PER_SAMPLE
+    bytes_per_launch = rows * nets_per_launch * LAYER_BYTES_PER_SAMPLE
+    ach_tf = flop_per_launch / (layer_ms * 1e-3) / 1e12
+    ach_gbs = bytes_per_launch / (layer_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_samples = rows * n_gpus * args.steps
+        value = total_samples / elapsed
+        n_layers = sum(len(d) for d in hp.model.dilations[:hp.model.n_iaf])
+        n_nets = hp.model.n_iaf * nets_per_launch
+        result = {
+            'metric': 'audio samples/sec, 4-flow IAF generation',
+            'value': value,
+            'unit': 'samples/s',
+            'n_gpus': n_gpus,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'f32' else args.precision,
+            'data': 'synthetic',
+            'x_realtime_22050': value / 22050.0,
+            'x_realtime_16000': value / 16000.0,
+            'config': {
+                'workload': '%s: %d IAF flows, %d WaveNets (%d dilated layers, R=D=64, S=128, W=2), %s conditioning, '
+                            '%d utterance(s) x %d samples per GPU (%.1f s @16 kHz; %d mel frames x %d mels, hop %d)'
+                            % (args.case, hp.model.n_iaf, n_nets, n_layers * nets_per_launch, hp.model.cond_upsample_method,
+                               utts, length, length / 16000.0, t_mel, n_mels, hop),
+                'case': args.case, 'utterances_per_gpu': utts, 'samples_per_utterance': length,
+                'parallelism': 'utterance-sharded x%d (no data-path collective)' % n_gpus,
+                'noise': 'logistic, sampled on device inside the step',
+            },
+            'roofline': {
+                'kernel': 'layer_f32_kernel<skip=0,cond=0,gated=0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
+                'bound': 'mfma', 'achieved': ach_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                'avg_launch_ms': layer_ms, 'launches_timed': len(res_ms),
+                'alg_flop_per_launch': flop_per_launch, 'alg_bytes_per_launch': bytes_per_launch,
+            },
+            'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                             'frac': ach_gbs / PEAK_HBM_GBS},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(ModelConfig.from_hparam(hp), args.cpu_seconds)
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

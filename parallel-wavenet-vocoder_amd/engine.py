@@ -25,6 +25,10 @@ from ._lib import HeadArgs, LayerArgs, check
 PRECISIONS = {'f32': _lib.PREC_F32, 'f16x3': _lib.PREC_F16X3}
 DEFAULT_PRECISION = 'f32'
 
+# When a list, run_nets brackets every fused-layer launch with HIP events recorded on the
+# launch stream and appends (tag, start_event, end_event): bench.py's live kernel timing.
+EVENT_LOG = None
+
 
 def _stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -280,7 +284,14 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
         a.skip_init = 1 if j == 0 else 0
         a.dilation = int(d)
         a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
-        check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s), 'pwv_wavenet_layer_f32')
+        if EVENT_LOG is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s), 'pwv_wavenet_layer_f32')
+            e1.record()
+            EVENT_LOG.append(('layer_gated' if last else 'layer_residual', e0, e1))
+        else:
+            check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s), 'pwv_wavenet_layer_f32')
         cur ^= 1
 
     # ---- post-processing head -----------------------------------------------------------------------

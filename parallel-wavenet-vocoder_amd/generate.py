@@ -1,0 +1,144 @@
+"""generate(case, ckpt, debug): mel-spectrogram -> waveform with the IAF-WaveNet student.
+
+Counterpart of /root/reference/generate.py:16-78 with the same arguments.  Differences that
+follow from the platform, not from the math:
+  * no TF graph/session: the forward is one call of IAFVocoder on the GPU (the reference's single
+    sess.run, generate.py:68);
+  * the checkpoint is read by variable NAME (EMA shadows preferred when hp.train.use_ema,
+    generate.py:55-66) from an .npz of TF-named arrays; with no checkpoint the model runs with
+    random init exactly like the reference ("No checkpoint found", generate.py:65-66);
+  * the result is written as .wav / .npy files into hp.logdir (the reference only writes
+    TensorBoard audio summaries, generate.py:71-73);
+  * `data_path: 'synthetic'` (bench cases) or a glob of .npy mel files replaces the wav dataset;
+    wav input uses the torch STFT front-end in audio_frontend.py.
+CLI (python-fire style, fire itself is not installed):  python -m pwv_amd.generate <case> [--ckpt=..] [--debug]
+"""
+from __future__ import absolute_import, division, print_function
+
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import engine
+from .hparam import hparam as hp
+from .models import IAFVocoder
+from .variables import reset_default_store
+
+
+def _latest_checkpoint(logdir):
+    """tf.train.latest_checkpoint analogue for .npz checkpoints: newest file in logdir."""
+    cands = sorted(glob.glob(os.path.join(logdir, '*.npz')), key=os.path.getmtime)
+    return cands[-1] if cands else None
+
+
+def _load_mels(data_path, batch_size, length, device):
+    """(gt_wav or None, melspec[N, t_mel, n_mels]) for the first `batch_size` items."""
+    hop, n_mels = hp.signal.hop_length, hp.signal.n_mels
+    t_mel = 1 + length // hop
+    if data_path == 'synthetic':
+        g = torch.Generator().manual_seed(0)
+        return None, (torch.rand((batch_size, t_mel, n_mels), generator=g) * 2 - 1).to(device)
+    files = sorted(glob.glob(data_path))
+    if not files:
+        raise FileNotFoundError('no input files match data_path %r (use data_path: synthetic for seeded noise mel)' % data_path)
+    # like data_load.py:22-25: the last (1 - dataset_ratio) share of the files is the generation split
+    split = int(len(files) * hp.train.dataset_ratio)
+    files = (files[split:] or files)[:batch_size]
+    print('dataset size is {}'.format(len(files)))
+    mels, wavs = [], []
+    for f in files:
+        if f.endswith('.npy'):
+            m = np.load(f).astype(np.float32)
+        else:
+            from .audio_frontend import wav_to_normalized_mel
+            wav, m = wav_to_normalized_mel(f, length)
+            wavs.append(wav)
+        if m.shape[0] < t_mel:
+            m = np.pad(m, [(0, t_mel - m.shape[0]), (0, 0)])
+        mels.append(m[:t_mel])
+    while len(mels) < batch_size:
+        mels.append(mels[-1])
+        if wavs:
+            wavs.append(wavs[-1])
+    gt = np.stack(wavs)[..., None] if wavs else None
+    return gt, torch.from_numpy(np.stack(mels)).to(device)
+
+
+def generate(case='default', ckpt=None, debug=False):
+    '''
+    :param case: experiment case name
+    :param ckpt: checkpoint to load model
+    :param debug: print per-stage timing (the reference hooks tfdbg here).
+    '''
+    hp.set_hparam_yaml(case)
+    if not torch.cuda.is_available():
+        raise RuntimeError('generate() needs an MI355X: the HIP path has no CPU fallback')
+    device = torch.device('cuda', torch.cuda.current_device())
+    logdir = os.environ.get('PWV_LOGDIR', hp.logdir)
+
+    store = reset_default_store(device=device)              # fresh "graph"
+    batch_size, length = hp.generate.batch_size, hp.generate.length
+    gt_wav, melspec = _load_mels(hp.data_path, batch_size, length, device)
+
+    model = IAFVocoder(batch_size=batch_size, length=length, store=store)
+
+    # load model
+    ckpt = '{}/{}'.format(logdir, ckpt) if ckpt else (_latest_checkpoint(logdir) if os.path.isdir(logdir) else None)
+    if ckpt:
+        n = store.load_npz(ckpt, use_ema=bool(hp.train.use_ema))
+        print('Successfully loaded checkpoint {} ({} variables)'.format(ckpt, n))
+    else:
+        print('No checkpoint found at {}.'.format(logdir))
+
+    if debug:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    pred = model(gt_wav, melspec, is_training=False)         # feed forward
+    if debug:
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print('forward: %.2f ms, %.3g samples/s (first call includes weight packing)' % (ms, batch_size * length / ms * 1e3))
+    pred_wav = pred.cpu().numpy()
+
+    try:
+        os.makedirs(logdir, exist_ok=True)
+        from scipy.io import wavfile
+        for i in range(pred_wav.shape[0]):
+            wavfile.write(os.path.join(logdir, 'pred_%d.wav' % i), hp.signal.sr, np.clip(pred_wav[i, :, 0], -1, 1))
+        np.save(os.path.join(logdir, 'pred_wav.npy'), pred_wav)
+        print('wrote %d waveform(s) to %s' % (pred_wav.shape[0], logdir))
+    except OSError as e:
+        print('could not write outputs to %s: %s' % (logdir, e))
+    print('Done.')
+    return pred_wav
+
+
+def _fire(fn, argv):
+    """Minimal python-fire work-alike: positionals, --name=value, --name value, --flag."""
+    pos, kw = [], {}
+    it = iter(argv)
+    for a in it:
+        if a.startswith('--'):
+            k, eq, v = a[2:].partition('=')
+            if not eq:
+                nxt = next(it, None)
+                if nxt is None or nxt.startswith('--'):
+                    kw[k] = True
+                    if nxt is not None:
+                        k2, eq2, v2 = nxt[2:].partition('=')
+                        kw[k2] = v2 if eq2 else True
+                    continue
+                v = nxt
+            kw[k.replace('-', '_')] = {'True': True, 'False': False}.get(v, v)
+        else:
+            pos.append(a)
+    return fn(*pos, **kw)
+
+
+if __name__ == '__main__':
+    _fire(generate, sys.argv[1:])
