@@ -21,6 +21,8 @@
 //   * fp32 arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains, 157 TFLOP/s peak).
 #include "pwv_common.h"
 
+#include <cstdlib>
+
 namespace pwv {
 
 // ---- packed layer layout (floats) ----------------------------------------------------
@@ -81,24 +83,24 @@ __device__ __forceinline__ float gate_act(float f, float g) {
     return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
 }
 
-// lane (t,h) loads its NCH 16-byte chunks (float offsets 8g + 4h) of one channels-last row
+// lane (t,h) loads its NCH 16-byte chunks (float offsets 8g + 4h) of one channels-last row.
+// `row` is always a valid address (callers clamp); `keep == false` zeroes the result with
+// v_cndmask instead of branching around the loads.
 template <int NCH>
-__device__ __forceinline__ void load_row(const float* __restrict__ row, int h, bool valid, float (&dst)[4 * NCH]) {
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int h, bool keep, float (&dst)[4 * NCH]) {
 #pragma unroll
     for (int g = 0; g < NCH; ++g) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (valid) v = *reinterpret_cast<const f32x4*>(row + 8 * g + 4 * h);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * g + 4 * h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[4 * g + e] = v[e];
+        for (int e = 0; e < 4; ++e) dst[4 * g + e] = keep ? v[e] : 0.f;
     }
 }
 
 template <int NCH>
-__device__ __forceinline__ void load_contig(const float* __restrict__ p, bool valid, float (&dst)[4 * NCH]) {
+__device__ __forceinline__ void load_contig(const float* __restrict__ p, float (&dst)[4 * NCH]) {
 #pragma unroll
     for (int g = 0; g < NCH; ++g) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (valid) v = *reinterpret_cast<const f32x4*>(p + 4 * g);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[4 * g + e] = v[e];
     }
@@ -116,32 +118,34 @@ struct TileRegs {
 };
 
 template <bool SKIP, bool COND>
-__device__ __forceinline__ void load_tile(const LayerParams& p, int net, int tile, int wave, int lane,
+__device__ __forceinline__ void load_tile(const LayerParams& p, int net, int unit, int lane,
                                           TileRegs<SKIP, COND>& r, bool skip_load) {
     const int h = lane >> 5;
     const int rows = p.N * p.T;
-    const int row = tile * 128 + wave * 32 + (lane & 31);
+    const int row = unit * 32 + (lane & 31);
     r.row = row;
     r.valid = row < rows;
-    const int n = row / p.T;
-    const int t = row - n * p.T;
-    const float* xrow = p.x_in[net] + (size_t)row * 64;
-    load_row<8>(xrow, h, r.valid, r.xc);
-    load_row<8>(xrow - (size_t)p.dilation * 64, h, r.valid && (t >= p.dilation), r.xb);
+
+    const int rc = r.valid ? row : rows - 1;          // clamped: loads never leave the tensor
+    const int n = rc / p.T;
+    const int t = rc - n * p.T;
+    const bool has_prev = t >= p.dilation;            // x[t-d] = 0 left of the utterance start
+    const float* xrow = p.x_in[net] + (size_t)rc * 64;
+    load_row<8>(xrow, h, true, r.xc);
+    load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, r.xb);
     int prow = 0;
     if (p.cond_hop > 0) prow = n * p.cond_frames + (t + p.cond_offset) / p.cond_hop;
-    load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.valid, r.pj);
-    if constexpr (COND) load_row<10>(p.cond + (size_t)row * kCondC, h, r.valid, r.cd);
+    load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.pj);
+    if constexpr (COND) load_row<10>(p.cond + (size_t)rc * kCondC, h, true, r.cd);
     if constexpr (SKIP) {
         // skip row [128]: chunk for (it, q) at float offset 32*it + 8*q + 4*h
         if (skip_load) {
-            const float* srow = p.skip[net] + (size_t)row * 128;
+            const float* srow = p.skip[net] + (size_t)rc * 128;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (r.valid) v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) r.sk[it * 16 + q * 4 + e] = v[e];
                 }
@@ -174,6 +178,7 @@ __device__ __forceinline__ void gemm_groups(const float* lds, int base, int lane
         } else {
             tail(n);
         }
+        __builtin_amdgcn_sched_barrier(0);   // reads first: a whole group of MFMAs covers their latency
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float b = bval(g * 4 + e);
@@ -188,10 +193,19 @@ __device__ __forceinline__ void gemm_groups(const float* lds, int base, int lane
     }
 }
 
-template <bool SKIP, bool COND, bool GATED>
-__global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
+// Work is handed out in 32-row units (one MFMA column tile = one wave's worth of samples).
+// WAVES = 4: one wave per SIMD with up to 512 registers; units are strided statically and the next
+//            unit's operands are prefetched into registers under the current unit's GEMM2.
+// WAVES = 8: two waves per SIMD (<= 256 registers each).  Waves pull units from a per-workgroup
+//            LDS counter and waves 4..7 (the second wave of each SIMD) run at raised priority, so
+//            the two waves of a SIMD drift out of phase: one wave's MFMAs cover the other's loads,
+//            gating, address arithmetic and stores (identical streams at equal priority stay in
+//            lockstep and hit their VALU sections together, leaving the matrix pipe idle).
+template <int WAVES, bool SKIP, bool COND, bool GATED>
+__global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams p) {
+    constexpr bool PREFETCH = WAVES == 4;
     constexpr int kLds = layer_floats(SKIP, COND);
-    __shared__ __attribute__((aligned(16))) float lds[kLds];
+    __shared__ __attribute__((aligned(16))) float lds[kLds + 4];   // +4: the unit counter
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -200,11 +214,13 @@ __global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
     const int net = blockIdx.x % p.G;
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
+    int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
 
     {   // one layer's weights -> LDS (packed order == LDS order)
         const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = tid; i < kLds / 4; i += 256) dst[i] = src[i];
+        for (int i = tid; i < kLds / 4; i += 64 * WAVES) dst[i] = src[i];
+        if (tid == 0) *unit_counter = 0;
     }
     __syncthreads();
 
@@ -214,17 +230,35 @@ __global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
     constexpr int NC8 = kCondC / 8;
 
     const int rows = p.N * p.T;
-    const int ntiles = (rows + 127) / 128;
+    const int units = (rows + 31) / 32;
     const bool skip_load = SKIP && !p.skip_init;
 
-    int tile = wg;
+    // this workgroup's contiguous share of the units
+    const int per_wg = (units + nwg - 1) / nwg;
+    const int u_begin = wg * per_wg;
+    const int u_end = (u_begin + per_wg < units) ? u_begin + per_wg : units;
+
+    auto grab = [&]() -> int {   // next unit for this wave (WAVES == 8)
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(unit_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return u_begin + __builtin_amdgcn_readfirstlane(v);
+    };
+
+    int unit;
     TileRegs<SKIP, COND> cur;
-    load_tile<SKIP, COND>(p, net, tile, wave, lane, cur, skip_load);
+    if constexpr (PREFETCH) {
+        unit = u_begin + wave;
+        load_tile<SKIP, COND>(p, net, unit, lane, cur, skip_load);
+    } else {
+        if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+        unit = grab();
+    }
 
     auto no_extra = [](int) {};
 
-    while (tile < ntiles) {
-        const int next = tile + nwg;
+    while (unit < u_end) {
+        const int next = PREFETCH ? unit + WAVES : 0;
+        if constexpr (!PREFETCH) load_tile<SKIP, COND>(p, net, unit, lane, cur, skip_load);
         // ---- GEMM1: [F;G][128 x 32t] = W1^T[128 x K] * [x[t-d]; x[t]; (cond[t])] -------------
         // accumulators start at P[frame(t)] (conditioning projection + filter/gate bias)
         f32x16 acc[4];
@@ -265,7 +299,11 @@ __global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
             });
         }
         gemm_groups<16, 2, 1, 2>(
-            lds, kA1, lane, acc, a, bx, [&](int g) { o[g] = gate_act(acc[0][g], acc[2][g]); },
+            lds, kA1, lane, acc, a, bx,
+            [&](int g) {
+                o[g] = gate_act(acc[0][g], acc[2][g]);
+                asm volatile("" : "+v"(o[g]));   // keep the gating inside this MFMA group (no sinking)
+            },
             [&](f32x4(&n)[4]) {
                 if constexpr (!GATED) {
                     n[0] = frag(lds, kA2, 0, 8, 0, lane);
@@ -277,9 +315,11 @@ __global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
             });
 
         // next tile's operands: in flight during GEMM2 / skip GEMM / stores
-        TileRegs<SKIP, COND> nx;   // rows past the end are predicated off inside load_tile
-        load_tile<SKIP, COND>(p, net, next, wave, lane, nx, skip_load);
-        __builtin_amdgcn_sched_barrier(0);
+        TileRegs<SKIP, COND> nx;   // rows past the end are clamped inside load_tile
+        if constexpr (PREFETCH) {
+            load_tile<SKIP, COND>(p, net, next, lane, nx, skip_load);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         float* orow = p.x_out[net] + (size_t)cur.row * 64;
         if constexpr (GATED) {
@@ -310,7 +350,10 @@ __global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
                 [&](int g) {
                     if (g < 4) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[16 + 4 * g + e] = gate_act(acc[1][4 * g + e], acc[3][4 * g + e]);
+                        for (int e = 0; e < 4; ++e) {
+                            o[16 + 4 * g + e] = gate_act(acc[1][4 * g + e], acc[3][4 * g + e]);
+                            asm volatile("" : "+v"(o[16 + 4 * g + e]));
+                        }
                     }
                 },
                 [&](f32x4(&n)[4]) {
@@ -354,8 +397,12 @@ __global__ __launch_bounds__(256) void layer_f32_kernel(const LayerParams p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        cur = nx;
-        tile = next;
+        if constexpr (PREFETCH) {
+            cur = nx;
+            unit = next;
+        } else {
+            unit = grab();
+        }
     }
 }
 
@@ -393,7 +440,7 @@ __global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
         f32x4 a[4];
         if constexpr (FROM_GATED) {
             float o[32];
-            load_row<8>(p.in[net] + (size_t)row * 64, h, valid, o);
+            load_row<8>(p.in[net] + (size_t)(valid ? row : rows - 1) * 64, h, true, o);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -410,13 +457,12 @@ __global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
                                         for (int i = 0; i < 4; ++i) n[i] = frag(lds, kHA1, i, 16, 0, lane);
                                     });
         } else {
-            const float* srow = p.in[net] + (size_t)row * 128;
+            const float* srow = p.in[net] + (size_t)(valid ? row : rows - 1) * 128;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (valid) v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
                 }
@@ -545,9 +591,22 @@ __global__ void pack_head_kernel(const float* skip, const float* skip_bias, cons
     out[idx] = v;
 }
 
+// waves per workgroup of the layer kernel: 8 (two per SIMD) unless PWV_LAYER_WAVES=4
+static int layer_waves() {
+    static int w = 0;
+    if (w == 0) {
+        const char* e = getenv("PWV_LAYER_WAVES");
+        w = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    return w;
+}
+
 template <bool SKIP, bool COND, bool GATED>
-static int launch_layer(const LayerParams& lp, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((layer_f32_kernel<SKIP, COND, GATED>), dim3(grid), dim3(256), 0, s, lp);
+static int launch_layer(const LayerParams& lp, int per_net4, int per_net8, hipStream_t s) {
+    if (layer_waves() == 4)
+        hipLaunchKernelGGL((layer_f32_kernel<4, SKIP, COND, GATED>), dim3(per_net4 * lp.G), dim3(256), 0, s, lp);
+    else
+        hipLaunchKernelGGL((layer_f32_kernel<8, SKIP, COND, GATED>), dim3(per_net8 * lp.G), dim3(512), 0, s, lp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "layer kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
@@ -642,20 +701,19 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     const int cus = device_cus();
     if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
     const long long rows = (long long)a->N * a->T;
-    const int ntiles = (int)((rows + 127) / 128);
     int per_net = (a->max_workgroups > 0 ? a->max_workgroups : cus) / a->G;
     if (per_net < 1) per_net = 1;
-    if (per_net > ntiles) per_net = ntiles;
-    const int grid = per_net * a->G;
+    const int nt4 = (int)((rows + 127) / 128), nt8 = (int)((rows + 255) / 256);   // >= 1 unit per wave
+    const int g4 = per_net < nt4 ? per_net : nt4, g8 = per_net < nt8 ? per_net : nt8;
     hipStream_t s = (hipStream_t)stream;
     const bool cond = a->cond != nullptr, gated = a->out_mode == PWV_OUT_GATED;
     PWV_CHECK_ARG(a->out_mode == PWV_OUT_GATED || a->out_mode == PWV_OUT_RESIDUAL, "pwv_wavenet_layer_f32: bad out_mode");
     if (any_skip) {
-        if (cond) return gated ? launch_layer<true, true, true>(lp, grid, s) : launch_layer<true, true, false>(lp, grid, s);
-        return gated ? launch_layer<true, false, true>(lp, grid, s) : launch_layer<true, false, false>(lp, grid, s);
+        if (cond) return gated ? launch_layer<true, true, true>(lp, g4, g8, s) : launch_layer<true, true, false>(lp, g4, g8, s);
+        return gated ? launch_layer<true, false, true>(lp, g4, g8, s) : launch_layer<true, false, false>(lp, g4, g8, s);
     }
-    if (cond) return gated ? launch_layer<false, true, true>(lp, grid, s) : launch_layer<false, true, false>(lp, grid, s);
-    return gated ? launch_layer<false, false, true>(lp, grid, s) : launch_layer<false, false, false>(lp, grid, s);
+    if (cond) return gated ? launch_layer<false, true, true>(lp, g4, g8, s) : launch_layer<false, true, false>(lp, g4, g8, s);
+    return gated ? launch_layer<false, false, true>(lp, g4, g8, s) : launch_layer<false, false, false>(lp, g4, g8, s);
 }
 
 int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
