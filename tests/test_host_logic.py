@@ -1,0 +1,117 @@
+"""CPU: hparam semantics (hparam.py:7-68), the variable store / TF naming, the fire-style CLI
+parser, and that the product path refuses CPU tensors instead of falling back."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iaf_oracle as O
+
+
+def test_hparam_cases_and_merge():
+    from pwv_amd.hparam import hparam as hp, merge_dict
+    hp.set_hparam_yaml('default')                      # unknown case name -> plain defaults (hparam.py:59)
+    assert hp.case == 'default' and hp.logdir == hp.logdir_path + '/default'
+    assert hp.signal.hop_length == 80 and hp.model.n_iaf == 4 and hp['model']['filter_width'] == 2
+    assert [len(d) for d in hp.model.dilations] == [10, 10, 10, 30]
+    assert hp.model.use_skip_connection is False and hp.model.cond_upsample_method == 'repeat'
+    assert hp.generate.length == 64000 and hp.generate.batch_size == 3
+    hp.set_hparam_yaml('test/tran')                    # user wins, defaults fill recursively
+    assert hp.model.cond_upsample_method == 'transposed_conv' and hp.model.n_iaf == 4
+    assert hp.train.batch_size == 1 and hp.train.lr == 0.0002
+    assert hp.data_path.endswith('slt/*.wav')          # case-level data_path under train:/generate: is inert
+    hp.set_hparam_yaml('bench/c1')                     # lists are replaced whole, not merged (hparam.py:17-24)
+    assert hp.model.dilations == [[1, 2, 4, 8, 16, 32, 64, 128]] and hp.model.n_iaf == 1
+    assert hp.data_path == 'synthetic'
+    hp.set_hparam_yaml('ema/len4000')                  # second YAML document
+    assert hp.train.num_gpu == 8 and hp.train.batch_size == 8
+    assert merge_dict({'a': {'x': 1}, 'l': [1]}, {'a': {'x': 2, 'y': 3}, 'l': [1, 2], 'b': 4}) == \
+        {'a': {'x': 1, 'y': 3}, 'l': [1], 'b': 4}
+    cfg = O.ModelConfig.from_hparam(hp.set_hparam_yaml('bench/c2'))
+    assert cfg.shared_nets and cfg.n_iaf == 4
+    hp.set_hparam_yaml('default')
+
+
+def test_variable_names_match_tf_graph():
+    """WaveNet creates exactly the TF variable names / shapes of SURVEY.md section 8 f-1."""
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore, variable_scope
+    store = VariableStore(device='cpu')
+    cfg = O.ModelConfig(dilations=[[1, 2, 4]], n_iaf=1)
+    with variable_scope('iaf_vocoder'), variable_scope('iaf0'):
+        nets = [WaveNet(1, [1, 2, 4], 2, 64, 64, 128, quantization_channels=1, use_biases=True,
+                        condition_channels=80, use_skip_connection=False, name=n, store=store)
+                for n in ('scalar', 'shifter')]
+    for net in nets:
+        net.causal_filter()
+        for j in range(3):
+            net.layer_variables(j, with_cond=True)
+        net.head_variables()
+    want = {k: v for k, v in O.variable_shapes(cfg).items() if '/iaf0/' in k}
+    got = {k: tuple(v.shape) for k, v in store.vars.items()}
+    assert got == want
+    # biases follow the reference's zeros_initializer, matrices are glorot-uniform bounded
+    assert float(store.vars['iaf_vocoder/iaf0/scalar/dilated_stack/layer0/filter_bias'].abs().max()) == 0.0
+    w = store.vars['iaf_vocoder/iaf0/scalar/dilated_stack/layer0/filter']
+    assert float(w.abs().max()) <= np.sqrt(6.0 / (2 * 64 + 2 * 64)) + 1e-7 and float(w.std()) > 0.05
+
+
+def test_store_ema_preference_and_shape_checks():
+    from pwv_amd.variables import EMA_SUFFIX, VariableStore
+    store = VariableStore(device='cpu')
+    ck = {'a/w': np.ones((2, 3), np.float32), 'a/w' + EMA_SUFFIX: np.full((2, 3), 5, np.float32),
+          'a/b': np.zeros(3, np.float32)}
+    assert store.load_dict(ck, use_ema=True) == 2          # generate.py:59-63: EMA shadow wins
+    assert float(store.vars['a/w'][0, 0]) == 5.0
+    store.load_dict(ck, use_ema=False)
+    assert float(store.vars['a/w'][0, 0]) == 1.0
+    v0 = store.version
+    assert store.get_variable('a/w', [2, 3]) is store.vars['a/w'] and store.version == v0
+    with pytest.raises(ValueError):
+        store.get_variable('a/w', [3, 2])
+    with pytest.raises(ValueError):
+        store.assign('a/w', np.zeros((4, 4)))
+
+
+def test_fire_style_cli():
+    from pwv_amd.generate import _fire
+    got = {}
+    def fn(case='default', ckpt=None, debug=False):
+        got.update(case=case, ckpt=ckpt, debug=debug)
+    _fire(fn, ['bench/c1'])
+    assert got == dict(case='bench/c1', ckpt=None, debug=False)
+    _fire(fn, ['test/tran', '--ckpt=model-100', '--debug'])
+    assert got == dict(case='test/tran', ckpt='model-100', debug=True)
+    _fire(fn, ['--case', 'ema/lj', '--ckpt', 'x'])
+    assert got == dict(case='ema/lj', ckpt='x', debug=False)
+
+
+def test_cpu_tensors_are_refused(built_lib):
+    """The product path has no CPU implementation: it raises instead of silently computing elsewhere."""
+    from pwv_amd import _lib
+    from pwv_amd.modules import causal_conv
+    with pytest.raises(_lib.PwvError, match='no CPU path'):
+        causal_conv(torch.zeros(1, 8, 4), torch.zeros(2, 4, 4), 1)
+
+
+def test_repeated_condition_validation():
+    from pwv_amd.engine import RepeatedCondition
+    frames = torch.zeros(2, 5, 80)
+    rc = RepeatedCondition(frames, 80, 40, 320)
+    assert rc.shape == (2, 320, 80)
+    with pytest.raises(ValueError):
+        RepeatedCondition(frames, 80, 40, 400)          # needs 6 frames
+
+
+def test_fused_supported_matrix():
+    from pwv_amd.engine import RepeatedCondition
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    st = VariableStore(device='cpu')
+    mk = lambda **kw: WaveNet(1, [1, 2], kw.pop('W', 2), kw.pop('R', 64), 64, 128, quantization_channels=1,
+                              condition_channels=kw.pop('C', 80), store=st, **kw)
+    rc = RepeatedCondition(torch.zeros(1, 3, 80), 80, 40, 160)
+    assert mk().fused_supported(None) and mk().fused_supported(rc) and mk().fused_supported(torch.zeros(1, 160, 80))
+    assert not mk(W=3).fused_supported(None) and not mk(R=32).fused_supported(None)
+    assert not mk(normalize='in').fused_supported(None)
+    assert not mk(C=40).fused_supported(torch.zeros(1, 160, 40))     # per-sample conditioning kernel is 80-channel
+    assert mk(C=40).fused_supported(RepeatedCondition(torch.zeros(1, 3, 40), 80, 40, 160))
