@@ -19,92 +19,11 @@
 //     value (frame-rate projection P), so the hoisted 'repeat' conditioning costs no FLOPs
 //     in this kernel; per-sample conditioning (transposed-conv upsampling) adds 40 k-steps.
 //   * fp32 arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains, 157 TFLOP/s peak).
-#include "pwv_common.h"
+#include "pwv_layer_common.h"
 
 #include <cstdlib>
 
 namespace pwv {
-
-// ---- packed layer layout (floats) ----------------------------------------------------
-constexpr int kA1 = 0;                    // [4 it][16 ks4][64 lane][4]   filter‖gate, K = 128
-constexpr int kA1Size = 4 * 16 * 64 * 4;  // 16384
-constexpr int kA2 = kA1 + kA1Size;        // [2 it][8 ks4][64][4]         dense, K = 64
-constexpr int kA2Size = 2 * 8 * 64 * 4;   // 4096
-constexpr int kBD = kA2 + kA2Size;        // [2 h][32]                    dense bias (D layout)
-constexpr int kBDSize = 64;
-constexpr int kLayerBase = kBD + kBDSize;  // 20544
-constexpr int kASSize = 4 * 8 * 64 * 4;    // 8192   skip, K = 64, 128 outputs
-constexpr int kBSSize = 128;               // [2 h][64]
-constexpr int kCondC = 80;                 // per-sample conditioning channels supported
-constexpr int kACSize = 4 * (kCondC / 8) * 64 * 4;  // 10240
-
-constexpr int layer_floats(bool skip, bool cond) {
-    return kLayerBase + (skip ? kASSize + kBSSize : 0) + (cond ? kACSize : 0);
-}
-
-// ---- packed head layout ----------------------------------------------------------------
-constexpr int kHAS = 0;                       // skip weights (as above)
-constexpr int kHBS = kHAS + kASSize;          // skip bias
-constexpr int kHA1 = kHBS + kBSSize;          // post1 [4 it][16 ks4][64][4]
-constexpr int kHA1Size = 4 * 16 * 64 * 4;
-constexpr int kHB1 = kHA1 + kHA1Size;         // post1 bias [2 h][64]
-constexpr int kHW2 = kHB1 + 128;              // post2 [2 h][Q][64], then bias [Q] (padded to 4)
-constexpr int kMaxQ = 4;
-constexpr int head_floats(int Q) { return kHW2 + 2 * Q * 64 + 4; }
-
-struct LayerParams {
-    const float* x_in[PWV_MAX_NETS];
-    float* x_out[PWV_MAX_NETS];
-    const float* packed[PWV_MAX_NETS];
-    const float* proj[PWV_MAX_NETS];
-    float* skip[PWV_MAX_NETS];
-    const float* cond;
-    int proj_row_stride;
-    int G, N, T, dilation;
-    int cond_hop, cond_offset, cond_frames;
-    int skip_init;
-};
-
-struct HeadParams {
-    const float* in[PWV_MAX_NETS];
-    const float* packed[PWV_MAX_NETS];
-    float* out[PWV_MAX_NETS];
-    int G, N, T, Q;
-};
-
-__device__ __forceinline__ float gate_act(float f, float g) {
-    // tanh(f) * sigmoid(g) = (1 - e^-2f) / ((1 + e^-2f)(1 + e^-g)); one v_rcp, two v_exp.
-    // clamps keep the product of the denominators finite; tanh(+-20) == +-1 in fp32,
-    // sigmoid(-40) = 4e-18.
-    f = fminf(fmaxf(f, -20.f), 20.f);
-    g = fminf(fmaxf(g, -40.f), 40.f);
-    const float e1 = __builtin_amdgcn_exp2f(f * -2.8853900817779268f);
-    const float e2 = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
-    return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
-}
-
-// lane (t,h) loads its NCH 16-byte chunks (float offsets 8g + 4h) of one channels-last row.
-// `row` is always a valid address (callers clamp); `keep == false` zeroes the result with
-// v_cndmask instead of branching around the loads.
-template <int NCH>
-__device__ __forceinline__ void load_row(const float* __restrict__ row, int h, bool keep, float (&dst)[4 * NCH]) {
-#pragma unroll
-    for (int g = 0; g < NCH; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * g + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[4 * g + e] = keep ? v[e] : 0.f;
-    }
-}
-
-template <int NCH>
-__device__ __forceinline__ void load_contig(const float* __restrict__ p, float (&dst)[4 * NCH]) {
-#pragma unroll
-    for (int g = 0; g < NCH; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[4 * g + e] = v[e];
-    }
-}
 
 template <bool SKIP, bool COND>
 struct TileRegs {
@@ -640,7 +559,10 @@ int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dens
     PWV_CHECK_ARG(cond_channels == 0 || cond_channels == kCondC,
                   "pwv_pack_layer_f32: per-sample conditioning supports %d channels, got %d", kCondC, cond_channels);
     PWV_CHECK_ARG(cond_channels == 0 || (gc_filter && gc_gate), "pwv_pack_layer_f32: gc weights missing");
-    PWV_CHECK_ARG(precision == PWV_PREC_F32, "pwv_pack_layer_f32: unsupported precision %d", precision);
+    PWV_CHECK_ARG(precision == PWV_PREC_F32 || precision == PWV_PREC_F16X3, "pwv_pack_layer_f32: unsupported precision %d", precision);
+    if (precision == PWV_PREC_F16X3)
+        return launch_pack_layer_f16x3(filter, gate, dense, dense_bias, skip, skip_bias, gc_filter, gc_gate, with_skip,
+                                       cond_channels, packed, (hipStream_t)stream);
     const int total = layer_floats(with_skip != 0, cond_channels > 0);
     hipLaunchKernelGGL(pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, filter, gate,
                        dense, dense_bias, skip, skip_bias, gc_filter, gc_gate, with_skip, cond_channels, packed, total);
@@ -653,7 +575,9 @@ int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* po
                       pwv_stream_t stream) {
     PWV_CHECK_ARG(post1 && post2 && packed, "pwv_pack_head_f32: NULL weight pointer");
     PWV_CHECK_ARG(Q >= 1 && Q <= kMaxQ, "pwv_pack_head_f32: Q must be in [1,%d], got %d", kMaxQ, Q);
-    PWV_CHECK_ARG(precision == PWV_PREC_F32, "pwv_pack_head_f32: unsupported precision %d", precision);
+    PWV_CHECK_ARG(precision == PWV_PREC_F32 || precision == PWV_PREC_F16X3, "pwv_pack_head_f32: unsupported precision %d", precision);
+    if (precision == PWV_PREC_F16X3)
+        return launch_pack_head_f16x3(skip, skip_bias, post1, post1_bias, post2, post2_bias, Q, packed, (hipStream_t)stream);
     const int total = head_floats(Q);
     hipLaunchKernelGGL(pack_head_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, skip, skip_bias,
                        post1, post1_bias, post2, post2_bias, Q, packed, total);
@@ -666,7 +590,7 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     PWV_CHECK_ARG(a->G >= 1 && a->G <= PWV_MAX_NETS, "pwv_wavenet_layer_f32: G=%d out of range", a->G);
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1 && a->dilation >= 1, "pwv_wavenet_layer_f32: bad N/T/dilation");
     PWV_CHECK_ARG((long long)a->N * a->T < (1ll << 31) - 256, "pwv_wavenet_layer_f32: N*T too large");
-    PWV_CHECK_ARG(a->precision == PWV_PREC_F32, "pwv_wavenet_layer_f32: unsupported precision %d", a->precision);
+    PWV_CHECK_ARG(a->precision == PWV_PREC_F32 || a->precision == PWV_PREC_F16X3, "pwv_wavenet_layer_f32: unsupported precision %d", a->precision);
     PWV_CHECK_ARG(a->cond_channels == 0 || a->cond_channels == kCondC,
                   "pwv_wavenet_layer_f32: per-sample conditioning supports %d channels", kCondC);
     PWV_CHECK_ARG((a->cond_channels > 0) == (a->cond != nullptr), "pwv_wavenet_layer_f32: cond / cond_channels mismatch");
@@ -708,6 +632,7 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool cond = a->cond != nullptr, gated = a->out_mode == PWV_OUT_GATED;
     PWV_CHECK_ARG(a->out_mode == PWV_OUT_GATED || a->out_mode == PWV_OUT_RESIDUAL, "pwv_wavenet_layer_f32: bad out_mode");
+    if (a->precision == PWV_PREC_F16X3) return launch_layer_f16x3(lp, any_skip, cond, gated, g8, s);
     if (any_skip) {
         if (cond) return gated ? launch_layer<true, true, true>(lp, g4, g8, s) : launch_layer<true, true, false>(lp, g4, g8, s);
         return gated ? launch_layer<true, false, true>(lp, g4, g8, s) : launch_layer<true, false, false>(lp, g4, g8, s);
@@ -722,7 +647,7 @@ int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_head_f32: bad N/T");
     PWV_CHECK_ARG((long long)a->N * a->T < (1ll << 31) - 256, "pwv_wavenet_head_f32: N*T too large");
     PWV_CHECK_ARG(a->Q >= 1 && a->Q <= kMaxQ, "pwv_wavenet_head_f32: Q must be in [1,%d]", kMaxQ);
-    PWV_CHECK_ARG(a->precision == PWV_PREC_F32, "pwv_wavenet_head_f32: unsupported precision %d", a->precision);
+    PWV_CHECK_ARG(a->precision == PWV_PREC_F32 || a->precision == PWV_PREC_F16X3, "pwv_wavenet_head_f32: unsupported precision %d", a->precision);
     PWV_CHECK_ARG(a->in_mode == PWV_HEAD_IN_GATED || a->in_mode == PWV_HEAD_IN_SKIPSUM, "pwv_wavenet_head_f32: bad in_mode");
     HeadParams hp{};
     for (int g = 0; g < a->G; ++g) {
@@ -743,6 +668,8 @@ int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
     if (per_net < 1) per_net = 1;
     if (per_net > ntiles) per_net = ntiles;
     const int grid = per_net * a->G;
+    if (a->precision == PWV_PREC_F16X3)
+        return launch_head_f16x3(hp, a->in_mode == PWV_HEAD_IN_GATED, grid, (hipStream_t)stream);
     if (a->in_mode == PWV_HEAD_IN_GATED)
         hipLaunchKernelGGL((head_f32_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, hp);
     else

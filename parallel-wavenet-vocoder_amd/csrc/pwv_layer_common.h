@@ -1,0 +1,100 @@
+// Layouts, kernel parameter blocks and device helpers shared by the fp32 (pwv_layer.hip) and
+// split-fp16 (pwv_layer_f16.hip) variants of the fused layer / head kernels.
+#pragma once
+
+#include "pwv_common.h"
+
+namespace pwv {
+
+// ---- packed layer layout (floats) ----------------------------------------------------
+constexpr int kA1 = 0;                    // [4 it][16 ks4][64 lane][4]   filter‖gate, K = 128
+constexpr int kA1Size = 4 * 16 * 64 * 4;  // 16384
+constexpr int kA2 = kA1 + kA1Size;        // [2 it][8 ks4][64][4]         dense, K = 64
+constexpr int kA2Size = 2 * 8 * 64 * 4;   // 4096
+constexpr int kBD = kA2 + kA2Size;        // [2 h][32]                    dense bias (D layout)
+constexpr int kBDSize = 64;
+constexpr int kLayerBase = kBD + kBDSize;  // 20544
+constexpr int kASSize = 4 * 8 * 64 * 4;    // 8192   skip, K = 64, 128 outputs
+constexpr int kBSSize = 128;               // [2 h][64]
+constexpr int kCondC = 80;                 // per-sample conditioning channels supported
+constexpr int kACSize = 4 * (kCondC / 8) * 64 * 4;  // 10240
+
+constexpr int layer_floats(bool skip, bool cond) {
+    return kLayerBase + (skip ? kASSize + kBSSize : 0) + (cond ? kACSize : 0);
+}
+
+// ---- packed head layout ----------------------------------------------------------------
+constexpr int kHAS = 0;                       // skip weights (as above)
+constexpr int kHBS = kHAS + kASSize;          // skip bias
+constexpr int kHA1 = kHBS + kBSSize;          // post1 [4 it][16 ks4][64][4]
+constexpr int kHA1Size = 4 * 16 * 64 * 4;
+constexpr int kHB1 = kHA1 + kHA1Size;         // post1 bias [2 h][64]
+constexpr int kHW2 = kHB1 + 128;              // post2 [2 h][Q][64], then bias [Q] (padded to 4)
+constexpr int kMaxQ = 4;
+constexpr int head_floats(int Q) { return kHW2 + 2 * Q * 64 + 4; }
+
+struct LayerParams {
+    const float* x_in[PWV_MAX_NETS];
+    float* x_out[PWV_MAX_NETS];
+    const float* packed[PWV_MAX_NETS];
+    const float* proj[PWV_MAX_NETS];
+    float* skip[PWV_MAX_NETS];
+    const float* cond;
+    int proj_row_stride;
+    int G, N, T, dilation;
+    int cond_hop, cond_offset, cond_frames;
+    int skip_init;
+};
+
+struct HeadParams {
+    const float* in[PWV_MAX_NETS];
+    const float* packed[PWV_MAX_NETS];
+    float* out[PWV_MAX_NETS];
+    int G, N, T, Q;
+};
+
+__device__ __forceinline__ float gate_act(float f, float g) {
+    // tanh(f) * sigmoid(g) = (1 - e^-2f) / ((1 + e^-2f)(1 + e^-g)); one v_rcp, two v_exp.
+    // clamps keep the product of the denominators finite; tanh(+-20) == +-1 in fp32,
+    // sigmoid(-40) = 4e-18.
+    f = fminf(fmaxf(f, -20.f), 20.f);
+    g = fminf(fmaxf(g, -40.f), 40.f);
+    const float e1 = __builtin_amdgcn_exp2f(f * -2.8853900817779268f);
+    const float e2 = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
+}
+
+// lane (t,h) loads its NCH 16-byte chunks (float offsets 8g + 4h) of one channels-last row.
+// `row` is always a valid address (callers clamp); `keep == false` zeroes the result with
+// v_cndmask instead of branching around the loads.
+template <int NCH>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int h, bool keep, float (&dst)[4 * NCH]) {
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * g + e] = keep ? v[e] : 0.f;
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_contig(const float* __restrict__ p, float (&dst)[4 * NCH]) {
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * g + e] = v[e];
+    }
+}
+
+
+// launchers of the split-fp16 variants (pwv_layer_f16.hip)
+int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, int per_net, hipStream_t s);
+int launch_head_f16x3(const HeadParams& hp, bool from_gated, int grid, hipStream_t s);
+int launch_pack_layer_f16x3(const float* filter, const float* gate, const float* dense, const float* dense_bias,
+                            const float* skip, const float* skip_bias, const float* gc_filter, const float* gc_gate,
+                            int with_skip, int cond_c, float* out, hipStream_t s);
+int launch_pack_head_f16x3(const float* skip, const float* skip_bias, const float* post1, const float* post1_bias,
+                           const float* post2, const float* post2_bias, int Q, float* out, hipStream_t s);
+
+}  // namespace pwv

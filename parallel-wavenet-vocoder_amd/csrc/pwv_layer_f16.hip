@@ -1,0 +1,634 @@
+// Split-fp16 ("f16x3") variants of the fused layer / head kernels for gfx950.
+//
+// Same math, layouts in HBM, register ownership and launch structure as pwv_layer.hip (the
+// reference call sites are /root/reference/modules.py:185-259 and :145-165), but the GEMMs run on
+// v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate) with error compensation:
+//
+//     w*x  ~=  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi,     v_hi = fp16(v),  v_lo = fp16(v - v_hi)
+//
+// accumulated in fp32.  fp16 products are exact in the fp32 accumulator; the dropped term w_lo*x_lo
+// is ~2^-22 |w x|, and each operand is represented to max(2^-22 |v|, 2^-25) (gfx950 keeps fp16
+// subnormals in MFMA inputs and conversions -- tools/probes/f16_denorm.hip -- so no rescaling of the
+// low parts is needed).  Activations stay fp32 in HBM; the split happens in registers.
+// Per 32-sample unit: 120 MFMAs x 32 cycles = 3,840 matrix cycles instead of 320 x 64 = 20,480.
+#include "pwv_layer_common.h"
+
+namespace pwv {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// registers x[OFF .. OFF+7] -> hi / lo fp16 fragments (one MFMA B operand each)
+template <int OFF, int N>
+__device__ __forceinline__ void split8(const float (&x)[N], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const f32x2 v = {x[OFF + q], x[OFF + q + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f32x2 r = v - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[q] = h[0];
+        hi[q + 1] = h[1];
+        lo[q] = l[0];
+        lo[q + 1] = l[1];
+    }
+}
+
+// A fragments live in LDS as 16-byte units: unit index ((comp*NITTOT + it)*NS + s)*64 + lane,
+// comp 0 = hi, 1 = lo; each unit = the 8 k values of k-step s this lane multiplies.
+template <int NS, int NITTOT>
+__device__ __forceinline__ f16x8 frag16(const f16x8* A, int comp, int it, int s, int lane) {
+    return A[((comp * NITTOT + it) * NS + s) * 64 + lane];
+}
+
+// One GEMM as NS groups (one k-step of 16 each) of NIT row tiles x 3 MFMAs.  Fragments of step
+// s+1 are read while step s's MFMAs issue (sched_barrier-pinned, see pwv_layer.hip).
+template <int NS, int NIT, int IT0, int ITSTEP, int NITTOT, int NACC, typename BH, typename BL, typename EF, typename TF>
+__device__ __forceinline__ void gemm16(const f16x8* A, int lane, f32x16 (&acc)[NACC], f16x8 (&ah)[4], f16x8 (&al)[4],
+                                       BH&& bh, BL&& bl, EF&& extra, TF&& tail) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f16x8 nh[4] = {ah[0], ah[1], ah[2], ah[3]};
+        f16x8 nl[4] = {al[0], al[1], al[2], al[3]};
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                nh[i] = frag16<NS, NITTOT>(A, 0, IT0 + i * ITSTEP, s + 1, lane);
+                nl[i] = frag16<NS, NITTOT>(A, 1, IT0 + i * ITSTEP, s + 1, lane);
+            }
+        } else {
+            tail(nh, nl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 b_h = bh(s);
+        const f16x8 b_l = bl(s);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b_h, acc[IT0 + i * ITSTEP], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b_l, acc[IT0 + i * ITSTEP], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b_h, acc[IT0 + i * ITSTEP], 0, 0, 0);
+        extra(s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = nh[i];
+            al[i] = nl[i];
+        }
+    }
+}
+
+template <int NS, int NIT, int IT0, int ITSTEP, int NITTOT>
+__device__ __forceinline__ void first_frags(const f16x8* A, int lane, f16x8 (&h)[4], f16x8 (&l)[4]) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        h[i] = frag16<NS, NITTOT>(A, 0, IT0 + i * ITSTEP, 0, lane);
+        l[i] = frag16<NS, NITTOT>(A, 1, IT0 + i * ITSTEP, 0, lane);
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// fused gated-residual layer, split-fp16 arithmetic (8 waves, dynamic 32-sample units)
+// --------------------------------------------------------------------------------------
+template <bool SKIP, bool COND, bool GATED>
+__global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
+    constexpr int WAVES = 8;
+    constexpr int kLds = layer_floats(SKIP, COND);
+    __shared__ __attribute__((aligned(16))) float lds[kLds + 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int net = blockIdx.x % p.G;
+    const int wg = blockIdx.x / p.G;
+    const int nwg = gridDim.x / p.G;
+    int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < kLds / 4; i += 64 * WAVES) dst[i] = src[i];
+        if (tid == 0) *unit_counter = 0;
+    }
+    __syncthreads();
+
+    constexpr int kAS = kLayerBase;
+    constexpr int kBS = kAS + kASSize;
+    constexpr int kAC = kLayerBase + (SKIP ? kASSize + kBSSize : 0);
+    const f16x8* A1 = reinterpret_cast<const f16x8*>(&lds[kA1]);
+    const f16x8* A2 = reinterpret_cast<const f16x8*>(&lds[kA2]);
+    const f16x8* AS = reinterpret_cast<const f16x8*>(&lds[kAS]);
+    const f16x8* AC = reinterpret_cast<const f16x8*>(&lds[kAC]);
+
+    const int rows = p.N * p.T;
+    const int units = (rows + 31) / 32;
+    const int per_wg = (units + nwg - 1) / nwg;
+    const int u_begin = wg * per_wg;
+    const int u_end = (u_begin + per_wg < units) ? u_begin + per_wg : units;
+    auto grab = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(unit_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return u_begin + __builtin_amdgcn_readfirstlane(v);
+    };
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    auto no_extra = [](int) {};
+
+    for (int unit = grab(); unit < u_end; unit = grab()) {
+        const int row = unit * 32 + (lane & 31);
+        const bool valid = row < rows;
+        const int rc = valid ? row : rows - 1;
+        const int n = rc / p.T;
+        const int t = rc - n * p.T;
+        const bool has_prev = t >= p.dilation;
+        const float* xrow = p.x_in[net] + (size_t)rc * 64;
+
+        f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
+        float xc[32];
+        {
+            float xb[32];
+            load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
+            load_row<8>(xrow, h, true, xc);
+            split8<0>(xb, bh[0], bl[0]);
+            split8<8>(xb, bh[1], bl[1]);
+            split8<16>(xb, bh[2], bl[2]);
+            split8<24>(xb, bh[3], bl[3]);
+            split8<0>(xc, bh[4], bl[4]);
+            split8<8>(xc, bh[5], bl[5]);
+            split8<16>(xc, bh[6], bl[6]);
+            split8<24>(xc, bh[7], bl[7]);
+        }
+        f16x8 ch[5], cl[5];      // per-sample condition, K = 80
+        if constexpr (COND) {
+            float cd[40];
+            load_row<10>(p.cond + (size_t)rc * kCondC, h, true, cd);
+            split8<0>(cd, ch[0], cl[0]);
+            split8<8>(cd, ch[1], cl[1]);
+            split8<16>(cd, ch[2], cl[2]);
+            split8<24>(cd, ch[3], cl[3]);
+            split8<32>(cd, ch[4], cl[4]);
+        }
+        // accumulators start at P[frame(t)]
+        f32x16 acc[4];
+        {
+            int prow = 0;
+            if (p.cond_hop > 0) prow = n * p.cond_frames + (t + p.cond_offset) / p.cond_hop;
+            const float* pr = p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
+                }
+        }
+
+        auto bxh = [&](int s) -> f16x8 { return bh[s]; };
+        auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+        auto bch = [&](int s) -> f16x8 { return ch[COND ? s : 0]; };
+        auto bcl = [&](int s) -> f16x8 { return cl[COND ? s : 0]; };
+
+        float o[32];
+        f16x8 oh[4], ol[4];      // gated output as B operand: k-step s <-> o tile s>>1, regs 8*(s&1)..+7
+        f16x8 ah[4], al[4];
+
+        // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]) ----------------------------------------
+        if constexpr (COND) {
+            first_frags<5, 2, 0, 2, 4>(AC, lane, ah, al);
+            gemm16<5, 2, 0, 2, 4>(AC, lane, acc, ah, al, bch, bcl, no_extra,
+                                  [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 0, 2, 4>(A1, lane, nh, nl); });
+        } else {
+            first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
+        }
+        gemm16<8, 2, 0, 2, 4>(A1, lane, acc, ah, al, bxh, bxl, no_extra, [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
+            if constexpr (COND) first_frags<5, 2, 1, 2, 4>(AC, lane, nh, nl);
+            else first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl);
+        });
+        // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -------------
+        if constexpr (COND) {
+            gemm16<5, 2, 1, 2, 4>(AC, lane, acc, ah, al, bch, bcl, no_extra,
+                                  [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
+        }
+        gemm16<8, 2, 1, 2, 4>(
+            A1, lane, acc, ah, al, bxh, bxl,
+            [&](int s) {
+                o[2 * s] = gate_act(acc[0][2 * s], acc[2][2 * s]);
+                o[2 * s + 1] = gate_act(acc[0][2 * s + 1], acc[2][2 * s + 1]);
+                asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
+                if (s == 3) {
+                    split8<0>(o, oh[0], ol[0]);
+                    asm volatile("" : "+v"(oh[0]), "+v"(ol[0]));
+                }
+                if (s == 7) {
+                    split8<8>(o, oh[1], ol[1]);
+                    asm volatile("" : "+v"(oh[1]), "+v"(ol[1]));
+                }
+            },
+            [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
+                if constexpr (!GATED) first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl);
+                else if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
+            });
+
+        float* orow = p.x_out[net] + (size_t)row * 64;
+        if constexpr (GATED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+            if constexpr (SKIP) {
+                split8<16>(o, oh[2], ol[2]);
+                split8<24>(o, oh[3], ol[3]);
+            }
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                }
+            }
+        } else {
+            // ---- GEMM2: dense 64 -> 64, accumulator starts at x[t] + dense_bias -------------------
+            f32x16 acc2[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bd = *reinterpret_cast<const f32x4*>(&lds[kBD + h * 32 + it * 16 + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bd[e];
+                }
+            gemm16<4, 2, 0, 1, 2>(
+                A2, lane, acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
+                [&](int s) {
+                    if (s < 2) {   // k-steps 0,1 use o tile 0; gate + split tile 1 under them
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[16 + 8 * s + e] = gate_act(acc[1][8 * s + e], acc[3][8 * s + e]);
+                        if (s == 0) split8<16>(o, oh[2], ol[2]);
+                        else split8<24>(o, oh[3], ol[3]);
+                        asm volatile("" : "+v"(oh[2 + (s & 1)]), "+v"(ol[2 + (s & 1)]));
+                    }
+                },
+                [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
+                    if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
+                });
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int it = g >> 2, q = g & 3;
+                    f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                }
+            }
+        }
+
+        if constexpr (SKIP) {
+            // ---- skip 64 -> 128, accumulated across layers ------------------------------------------
+            f32x16 accs[4];
+            float* srow = p.skip[net] + (size_t)rc * 128;
+            const bool skip_load = !p.skip_init;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kBS + h * 64 + it * 16 + q * 4]);
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (skip_load) v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e] + bs[e];
+                }
+            gemm16<4, 4, 0, 1, 4>(AS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; },
+                                  [&](int s) -> f16x8 { return ol[s]; }, no_extra, [](f16x8(&)[4], f16x8(&)[4]) {});
+            if (valid) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(srow + 32 * it + 8 * q + 4 * h) = v;
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// head, split-fp16 arithmetic (4 waves, static tiles; post2 stays an fp32 VALU dot)
+// --------------------------------------------------------------------------------------
+template <bool FROM_GATED>
+__global__ __launch_bounds__(256) void head_f16x3_kernel(const HeadParams p) {
+    constexpr int kLds = head_floats(kMaxQ);
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int net = blockIdx.x % p.G;
+    const int wg = blockIdx.x / p.G;
+    const int nwg = gridDim.x / p.G;
+    const int Q = p.Q;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        const int n4 = head_floats(Q) / 4;
+        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const f16x8* HAS = reinterpret_cast<const f16x8*>(&lds[kHAS]);
+    const f16x8* HA1 = reinterpret_cast<const f16x8*>(&lds[kHA1]);
+    auto no_extra = [](int) {};
+    const int rows = p.N * p.T;
+    const int ntiles = (rows + 127) / 128;
+    for (int tile = wg; tile < ntiles; tile += nwg) {
+        const int row = tile * 128 + wave * 32 + (lane & 31);
+        const bool valid = row < rows;
+        const int rc = valid ? row : rows - 1;
+        f32x16 accs[4];
+        f16x8 ah[4], al[4];
+        if constexpr (FROM_GATED) {
+            f16x8 oh[4], ol[4];
+            {
+                float o[32];
+                load_row<8>(p.in[net] + (size_t)rc * 64, h, true, o);
+                split8<0>(o, oh[0], ol[0]);
+                split8<8>(o, oh[1], ol[1]);
+                split8<16>(o, oh[2], ol[2]);
+                split8<24>(o, oh[3], ol[3]);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kHBS + h * 64 + it * 16 + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = bs[e];
+                }
+            first_frags<4, 4, 0, 1, 4>(HAS, lane, ah, al);
+            gemm16<4, 4, 0, 1, 4>(HAS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; },
+                                  [&](int s) -> f16x8 { return ol[s]; }, no_extra,
+                                  [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 4, 0, 1, 4>(HA1, lane, nh, nl); });
+        } else {
+            const float* srow = p.in[net] + (size_t)rc * 128;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                }
+            first_frags<8, 4, 0, 1, 4>(HA1, lane, ah, al);
+        }
+        // relu -> split -> post1 (128 -> 128)
+        f16x8 sh[8], sl[8];
+        {
+            float r[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
+            split8<0>(r, sh[0], sl[0]);
+            split8<8>(r, sh[1], sl[1]);
+            split8<16>(r, sh[2], sl[2]);
+            split8<24>(r, sh[3], sl[3]);
+            split8<32>(r, sh[4], sl[4]);
+            split8<40>(r, sh[5], sl[5]);
+            split8<48>(r, sh[6], sl[6]);
+            split8<56>(r, sh[7], sl[7]);
+        }
+        f32x16 acc1[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&lds[kHB1 + h * 64 + it * 16 + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = b1[e];
+            }
+        gemm16<8, 4, 0, 1, 4>(HA1, lane, acc1, ah, al, [&](int s) -> f16x8 { return sh[s]; },
+                              [&](int s) -> f16x8 { return sl[s]; }, no_extra, [](f16x8(&)[4], f16x8(&)[4]) {});
+        for (int q = 0; q < Q; ++q) {
+            float part = 0.f;
+            const float* w2 = &lds[kHW2 + (h * Q + q) * 64];
+#pragma unroll
+            for (int i4 = 0; i4 < 16; ++i4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + 4 * i4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * i4 + e;
+                    part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[e], part);
+                }
+            }
+            part += __shfl_xor(part, 32);
+            part += lds[kHW2 + 2 * Q * 64 + q];
+            if (valid && h == 0) p.out[net][(size_t)row * Q + q] = part;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// packing: TF layouts -> hi/lo fp16 A fragments (+ fp32 bias sections, same offsets as fp32 layout)
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_split(f16x8* dst, int comp, const float (&w)[8]) {
+    f16x8 v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const _Float16 hi = (_Float16)w[q];
+        v[q] = comp == 0 ? hi : (_Float16)(w[q] - (float)hi);
+    }
+    *dst = v;
+}
+
+// decode unit index within a [comp][NITTOT][NS][64] section
+#define PWV_DECODE(u, NITTOT, NS)                                                     \
+    const int lane = (u) & 63, s = ((u) >> 6) % (NS), it = ((u) >> 6) / (NS) % (NITTOT), \
+              comp = ((u) >> 6) / ((NS) * (NITTOT));                                   \
+    const int h = lane >> 5, i = lane & 31;                                          \
+    (void)h; (void)i; (void)s; (void)it; (void)comp;
+
+__global__ void pack_layer_f16_kernel(const float* filter, const float* gate, const float* dense, const float* dense_bias,
+                                      const float* skip, const float* skip_bias, const float* gc_filter,
+                                      const float* gc_gate, int with_skip, int cond_c, float* out, int total_units) {
+    int u = blockIdx.x * blockDim.x + threadIdx.x;   // 16-byte units
+    if (u >= total_units) return;
+    f16x8* o16 = reinterpret_cast<f16x8*>(out);
+    f32x4* o32 = reinterpret_cast<f32x4*>(out);
+    float w[8];
+    const int base = u;
+    if (u < kA1Size / 4) {
+        PWV_DECODE(u, 4, 8)
+        const int tap = s >> 2, oc = 32 * it + i;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cin = 16 * (s & 3) + 8 * (q >> 2) + 4 * h + (q & 3);
+            w[q] = oc < 64 ? filter[(tap * 64 + cin) * 64 + oc] : gate[(tap * 64 + cin) * 64 + oc - 64];
+        }
+        put_split(&o16[base], comp, w);
+        return;
+    }
+    u -= kA1Size / 4;
+    if (u < kA2Size / 4) {
+        PWV_DECODE(u, 2, 4)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = dense[chan_of(s >> 1, 8 * (s & 1) + q, h) * 64 + 32 * it + i];
+        put_split(&o16[base], comp, w);
+        return;
+    }
+    u -= kA2Size / 4;
+    if (u < kBDSize / 4) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = u * 4 + e, hh = j >> 5, it = (j >> 4) & 1, r = j & 15;
+            v[e] = dense_bias ? dense_bias[chan_of(it, r, hh)] : 0.f;
+        }
+        o32[base] = v;
+        return;
+    }
+    u -= kBDSize / 4;
+    if (with_skip) {
+        if (u < kASSize / 4) {
+            PWV_DECODE(u, 4, 4)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = skip[chan_of(s >> 1, 8 * (s & 1) + q, h) * 128 + 32 * it + i];
+            put_split(&o16[base], comp, w);
+            return;
+        }
+        u -= kASSize / 4;
+        if (u < kBSSize / 4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = u * 4 + e, hh = j >> 6, it = (j >> 4) & 3, r = j & 15;
+                v[e] = skip_bias ? skip_bias[chan_of(it, r, hh)] : 0.f;
+            }
+            o32[base] = v;
+            return;
+        }
+        u -= kBSSize / 4;
+    }
+    if (cond_c > 0) {
+        PWV_DECODE(u, 4, 5)
+        const int oc = 32 * it + i;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ci = 16 * s + 8 * (q >> 2) + 4 * h + (q & 3);
+            w[q] = oc < 64 ? gc_filter[ci * 64 + oc] : gc_gate[ci * 64 + oc - 64];
+        }
+        put_split(&o16[base], comp, w);
+    }
+}
+
+__global__ void pack_head_f16_kernel(const float* skip, const float* skip_bias, const float* post1,
+                                     const float* post1_bias, const float* post2, const float* post2_bias, int Q,
+                                     float* out, int total_floats) {
+    // units of 16 bytes up to kHW2, then plain floats (post2 / its bias)
+    int u = blockIdx.x * blockDim.x + threadIdx.x;
+    f16x8* o16 = reinterpret_cast<f16x8*>(out);
+    f32x4* o32 = reinterpret_cast<f32x4*>(out);
+    const int base = u;
+    float w[8];
+    if (u < kASSize / 4) {
+        PWV_DECODE(u, 4, 4)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = skip ? skip[chan_of(s >> 1, 8 * (s & 1) + q, h) * 128 + 32 * it + i] : 0.f;
+        put_split(&o16[base], comp, w);
+        return;
+    }
+    u -= kASSize / 4;
+    if (u < kBSSize / 4) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = u * 4 + e, hh = j >> 6, it = (j >> 4) & 3, r = j & 15;
+            v[e] = skip_bias ? skip_bias[chan_of(it, r, hh)] : 0.f;
+        }
+        o32[base] = v;
+        return;
+    }
+    u -= kBSSize / 4;
+    if (u < kHA1Size / 4) {
+        PWV_DECODE(u, 4, 8)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = post1[chan_of(s >> 1, 8 * (s & 1) + q, h) * 128 + 32 * it + i];
+        put_split(&o16[base], comp, w);
+        return;
+    }
+    u -= kHA1Size / 4;
+    if (u < 128 / 4) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = u * 4 + e, hh = j >> 6, it = (j >> 4) & 3, r = j & 15;
+            v[e] = post1_bias ? post1_bias[chan_of(it, r, hh)] : 0.f;
+        }
+        o32[base] = v;
+        return;
+    }
+    u -= 128 / 4;
+    // post2 [2 h][Q][64] floats then bias (padded to 4)
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = u * 4 + e;
+        float x = 0.f;
+        if (j < 2 * Q * 64) {
+            const int c = j & 63, hq = j >> 6, q = hq % Q, hh = hq / Q;
+            x = post2[chan_of(c >> 4, c & 15, hh) * Q + q];
+        } else if (j - 2 * Q * 64 < Q && post2_bias) {
+            x = post2_bias[j - 2 * Q * 64];
+        }
+        v[e] = x;
+    }
+    if (base * 4 < total_floats) o32[base] = v;
+}
+
+template <bool SKIP, bool COND, bool GATED>
+static int launch16(const LayerParams& lp, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED>), dim3(grid), dim3(512), 0, s, lp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 layer kernel launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, int per_net, hipStream_t s) {
+    const int grid = per_net * lp.G;
+    if (skip) {
+        if (cond) return gated ? launch16<true, true, true>(lp, grid, s) : launch16<true, true, false>(lp, grid, s);
+        return gated ? launch16<true, false, true>(lp, grid, s) : launch16<true, false, false>(lp, grid, s);
+    }
+    if (cond) return gated ? launch16<false, true, true>(lp, grid, s) : launch16<false, true, false>(lp, grid, s);
+    return gated ? launch16<false, false, true>(lp, grid, s) : launch16<false, false, false>(lp, grid, s);
+}
+
+int launch_head_f16x3(const HeadParams& hp, bool from_gated, int grid, hipStream_t s) {
+    if (from_gated)
+        hipLaunchKernelGGL((head_f16x3_kernel<true>), dim3(grid), dim3(256), 0, s, hp);
+    else
+        hipLaunchKernelGGL((head_f16x3_kernel<false>), dim3(grid), dim3(256), 0, s, hp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 head kernel launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+int launch_pack_layer_f16x3(const float* filter, const float* gate, const float* dense, const float* dense_bias,
+                            const float* skip, const float* skip_bias, const float* gc_filter, const float* gc_gate,
+                            int with_skip, int cond_c, float* out, hipStream_t s) {
+    const int units = layer_floats(with_skip != 0, cond_c > 0) / 4;
+    hipLaunchKernelGGL(pack_layer_f16_kernel, dim3((units + 255) / 256), dim3(256), 0, s, filter, gate, dense,
+                       dense_bias, skip, skip_bias, gc_filter, gc_gate, with_skip, cond_c, out, units);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 pack launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+int launch_pack_head_f16x3(const float* skip, const float* skip_bias, const float* post1, const float* post1_bias,
+                           const float* post2, const float* post2_bias, int Q, float* out, hipStream_t s) {
+    const int total = head_floats(Q);
+    const int units = (total + 3) / 4;
+    hipLaunchKernelGGL(pack_head_f16_kernel, dim3((units + 255) / 256), dim3(256), 0, s, skip, skip_bias, post1,
+                       post1_bias, post2, post2_bias, Q, out, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 pack launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+}  // namespace pwv

@@ -14,6 +14,7 @@ Data layout in HBM (all float32, channels-last):
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_void_p
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -22,8 +23,12 @@ import torch
 from . import _lib
 from ._lib import HeadArgs, LayerArgs, check
 
+# 'f32'  : v_mfma_f32_32x32x2_f32, exact fp32 fma chains (157 TFLOP/s class)
+# 'f16x3': 3-term split-fp16 MFMA with fp32 accumulation (w*x ~= wh*xh + wh*xl + wl*xh, ~22-bit
+#          mantissa products): same measured accuracy vs fp64 as 'f32' (~3e-6 on the full model,
+#          bar 2e-5), 5.3x fewer matrix-pipe cycles.  Default; PWV_PRECISION overrides.
 PRECISIONS = {'f32': _lib.PREC_F32, 'f16x3': _lib.PREC_F16X3}
-DEFAULT_PRECISION = 'f32'
+DEFAULT_PRECISION = os.environ.get('PWV_PRECISION', 'f16x3')
 
 # When a list, run_nets brackets every fused-layer launch with HIP events recorded on the
 # launch stream and appends (tag, start_event, end_event): bench.py's live kernel timing.
@@ -176,7 +181,7 @@ _plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
 
 
 def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
-    key = (id(net.store), net.full_scope, cond_mode, precision)
+    key = (net.store.uid, net.full_scope, cond_mode, precision)
     hit = _plan_cache.get(key)
     if hit is not None and hit[0] == net.store.version:
         return hit[1]

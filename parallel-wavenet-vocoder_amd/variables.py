@@ -21,7 +21,11 @@ EMA_SUFFIX = '/ExponentialMovingAverage'
 
 
 class VariableStore:
+    _uid_counter = 0
+
     def __init__(self, device: Optional[torch.device] = None, seed: int = 2):
+        VariableStore._uid_counter += 1
+        self.uid = VariableStore._uid_counter      # never reused (id() can be, after garbage collection)
         self.device = torch.device(device) if device is not None else None
         self.seed = seed
         self.vars: Dict[str, torch.Tensor] = {}

@@ -14,12 +14,13 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 @pytest.mark.parametrize('name', sorted(VOCODER_CASES))
-def test_golden_vocoder_hip(gpu, name):
+def test_golden_vocoder_hip(gpu, name, precision):
     z = np.load(os.path.join(GOLD, name + '.npz'))
     cfg = O.ModelConfig(**json.loads(str(z['cfg'])))
     w = O.init_weights(cfg, seed=int(z['weight_seed']))
-    got = run_vocoder_hip(cfg, w, z['mel'], z['z'], gpu)
+    got = run_vocoder_hip(cfg, w, z['mel'], z['z'], gpu, precision=precision)
     err = np.abs(got - z['y']).max()
     assert got.shape == z['y'].shape and err <= TOL_F32, err
 

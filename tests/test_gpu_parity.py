@@ -52,7 +52,10 @@ def test_linear(gpu, M, K, Nout, relu, bias):
     assert np.abs(got - want).max() <= 1e-5
 
 
-def _wavenet_case(gpu, cond_mode, use_skip, use_biases, q_out, T=300, N=2, dil=(1, 2, 4, 8, 16)):
+PRECS = ['f32', 'f16x3']
+
+
+def _wavenet_case(gpu, cond_mode, use_skip, use_biases, q_out, T=300, N=2, dil=(1, 2, 4, 8, 16), precision='f32'):
     import torch
     from pwv_amd.engine import RepeatedCondition
     from pwv_amd.modules import WaveNet
@@ -84,7 +87,7 @@ def _wavenet_case(gpu, cond_mode, use_skip, use_biases, q_out, T=300, N=2, dil=(
         net = WaveNet(batch_size=N, dilations=list(dil), filter_width=2, residual_channels=64, dilation_channels=64,
                       skip_channels=128, quantization_channels=q_out, input_channels=1, use_biases=use_biases,
                       condition_channels=80 if cond_mode != 'none' else None, use_skip_connection=use_skip,
-                      name=net_name, store=store)
+                      name=net_name, store=store, precision=precision)
     assert net.fused_supported(cond_dev)
     got = net(_t(x, gpu), cond_dev)
     torch.cuda.synchronize()
@@ -94,50 +97,84 @@ def _wavenet_case(gpu, cond_mode, use_skip, use_biases, q_out, T=300, N=2, dil=(
     assert err <= TOL_F32, err
 
 
+@pytest.mark.parametrize('precision', PRECS)
 @pytest.mark.parametrize('cond_mode', ['frames', 'none', 'samples'])
 @pytest.mark.parametrize('use_skip', [False, True])
-def test_wavenet_fused(gpu, cond_mode, use_skip):
-    _wavenet_case(gpu, cond_mode, use_skip, use_biases=True, q_out=1, T=320)
+def test_wavenet_fused(gpu, cond_mode, use_skip, precision):
+    _wavenet_case(gpu, cond_mode, use_skip, use_biases=True, q_out=1, T=320, precision=precision)
 
 
-def test_wavenet_no_biases_q2(gpu):
-    _wavenet_case(gpu, 'frames', False, use_biases=False, q_out=2, T=240)
+@pytest.mark.parametrize('precision', PRECS)
+def test_wavenet_no_biases_q2(gpu, precision):
+    _wavenet_case(gpu, 'frames', False, use_biases=False, q_out=2, T=240, precision=precision)
 
 
-def test_wavenet_ragged_tail_and_big_dilation(gpu):
-    # T not a multiple of the 128-row tile, dilation larger than a tile and larger than T/2
-    _wavenet_case(gpu, 'none', False, True, 1, T=333, N=3, dil=(1, 512, 2, 256, 128))
+@pytest.mark.parametrize('precision', PRECS)
+def test_wavenet_ragged_tail_and_big_dilation(gpu, precision):
+    # T not a multiple of the 32-row unit, dilation larger than a tile and larger than T/2
+    _wavenet_case(gpu, 'none', False, True, 1, T=333, N=3, dil=(1, 512, 2, 256, 128), precision=precision)
 
 
+@pytest.mark.parametrize('precision', PRECS)
 @pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
-def test_vocoder_small(gpu, method):
+def test_vocoder_small(gpu, method, precision):
     cfg = small_cfg(cond_upsample_method=method)
     weights = O.init_weights(cfg, seed=2)
     mel, z = O.synthetic_inputs(2, 480, cfg)
     want = O.iaf_vocoder_forward(weights, mel, z, cfg)
-    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     err = np.abs(got - want).max()
     assert got.shape == want.shape and err <= TOL_F32, err
 
 
-def test_vocoder_default_model_1s(gpu):
+@pytest.mark.parametrize('precision', PRECS)
+def test_vocoder_default_model_1s(gpu, precision):
     """The reference-default model (4 flows, 8 nets, 120 layers) on 0.5 s of synthetic mel."""
     cfg = O.ModelConfig()
     weights = O.init_weights(cfg, seed=2)
     mel, z = O.synthetic_inputs(1, 8000, cfg)
     want = O.iaf_vocoder_forward(weights, mel, z, cfg)
-    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     err = np.abs(got - want).max()
     assert err <= TOL_F32, err
 
 
-def test_vocoder_shared_nets(gpu):
+@pytest.mark.parametrize('precision', PRECS)
+def test_vocoder_shared_nets(gpu, precision):
     cfg = small_cfg(shared_nets=True)
     weights = O.init_weights(cfg, seed=2)
     mel, z = O.synthetic_inputs(2, 400, cfg)
     want = O.iaf_vocoder_forward(weights, mel, z, cfg)
-    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     assert np.abs(got - want).max() <= TOL_F32
+
+
+@pytest.mark.parametrize('zscale,wscale', [(100, 1), (20, 2), (100, 4)])
+def test_large_magnitude_activations_f16x3(gpu, zscale, wscale):
+    """The split keeps ~22 mantissa bits at any scale inside fp16's range: with inputs 20-100x larger and
+    weights up to 4x larger (outputs up to ~4e5, heavy cancellation) the split-fp16 path must stay as close
+    to the fp64 oracle as the exact-fp32 path does (both lose the same digits to conditioning)."""
+    cfg = small_cfg()
+    weights = {k: (v * wscale if v.ndim > 1 else v) for k, v in O.init_weights(cfg, seed=6).items()}
+    mel, z = O.synthetic_inputs(1, 480, cfg)
+    z = z * zscale
+    want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+    e16 = np.abs(run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3') - want).max()
+    e32 = np.abs(run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f32') - want).max()
+    scale = max(1.0, np.abs(want).max())
+    assert np.isfinite(e16) and e16 <= max(3 * e32, 2e-5 * scale) and e16 <= 2e-4 * scale, (e16, e32, scale)
+
+
+def test_plan_cache_is_per_store(gpu):
+    """Packed-weight plans are keyed by a never-reused store uid: a new store with different weights under
+    the same scope names must not see the previous store's packed weights."""
+    cfg = small_cfg()
+    mel, z = O.synthetic_inputs(1, 240, cfg)
+    for seed in (11, 12, 13):
+        weights = O.init_weights(cfg, seed=seed)
+        want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+        got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+        assert np.abs(got - want).max() <= TOL_F32
 
 
 def test_upsample_cond_api(gpu):

@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--wgs', type=int, default=0)
     ap.add_argument('--dilation', type=int, default=64)
     ap.add_argument('--G', type=int, default=2)
-    ap.add_argument('--precision', type=int, default=0)
+    ap.add_argument('--precision', type=int, default=0, help='0 = f32, 1 = f16x3')
     args = ap.parse_args()
     _lib.build_library()
     lib = _lib.lib()
