@@ -621,6 +621,10 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     lp.cond_offset = a->cond_offset;
     lp.cond_frames = a->cond_frames;
     lp.skip_init = a->skip_init;
+    lp.trace = nullptr;
+#ifdef PWV_TRACE
+    { const char* e = getenv("PWV_TRACE_PTR"); if (e) lp.trace = (long long*)strtoull(e, nullptr, 0); }
+#endif
 
     const int cus = device_cus();
     if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");

@@ -44,7 +44,19 @@ struct LayerParams {
     int G, N, T, dilation;
     int cond_hop, cond_offset, cond_frames;
     int skip_init;
+    long long* trace;   // debug builds only (-DPWV_TRACE): per-wave phase timestamps
 };
+
+// -DPWV_TRACE: waves of workgroup 0 record s_memtime at phase boundaries (tools/trace_layer.py)
+#ifdef PWV_TRACE
+#define PWV_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        if (p.trace && blockIdx.x < 2 && lane == 0 && tr_unit < 8)                        \
+            p.trace[((blockIdx.x * 8 + wave) * 8 + tr_unit) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PWV_STAMP(slot) do {} while (0)
+#endif
 
 struct HeadParams {
     const float* in[PWV_MAX_NETS];

@@ -135,7 +135,11 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
     auto no_extra = [](int) {};
 
+    int tr_unit = -1;
+    (void)tr_unit;
     for (int unit = grab(); unit < u_end; unit = grab()) {
+        ++tr_unit;
+        PWV_STAMP(0);
         const int row = unit * 32 + (lane & 31);
         const bool valid = row < rows;
         const int rc = valid ? row : rows - 1;
@@ -150,6 +154,11 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             float xb[32];
             load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
             load_row<8>(xrow, h, true, xc);
+#ifdef PWV_TRACE
+            PWV_STAMP(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PWV_STAMP(2);
+#endif
             split8<0>(xb, bh[0], bl[0]);
             split8<8>(xb, bh[1], bl[1]);
             split8<16>(xb, bh[2], bl[2]);
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         auto bch = [&](int s) -> f16x8 { return ch[COND ? s : 0]; };
         auto bcl = [&](int s) -> f16x8 { return cl[COND ? s : 0]; };
 
+        PWV_STAMP(3);
         float o[32];
         f16x8 oh[4], ol[4];      // gated output as B operand: k-step s <-> o tile s>>1, regs 8*(s&1)..+7
         f16x8 ah[4], al[4];
@@ -206,6 +216,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             if constexpr (COND) first_frags<5, 2, 1, 2, 4>(AC, lane, nh, nl);
             else first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl);
         });
+        PWV_STAMP(4);
         // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -------------
         if constexpr (COND) {
             gemm16<5, 2, 1, 2, 4>(AC, lane, acc, ah, al, bch, bcl, no_extra,
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 else if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
             });
 
+        PWV_STAMP(5);
         float* orow = p.x_out[net] + (size_t)row * 64;
         if constexpr (GATED) {
 #pragma unroll
@@ -271,6 +283,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
                     if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
                 });
+            PWV_STAMP(6);
             if (valid) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
@@ -279,6 +292,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                     *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
                 }
             }
+            PWV_STAMP(7);
         }
 
         if constexpr (SKIP) {

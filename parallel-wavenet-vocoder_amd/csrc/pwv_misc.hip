@@ -54,30 +54,44 @@ __global__ void causal_conv_kernel(const float* __restrict__ x, const float* __r
 
 // --------------------------------------------------------------------------------------
 // y[M,Nout] = act(x[M,K] @ w[K,Nout] + bias): fp32 MFMA (v_mfma_f32_32x32x2_f32).
-// MFMA rows = output columns n, MFMA columns = rows m; a wave owns 32 rows m and keeps its
-// x rows in registers (lane (m,h) holds k in [h*K/2, (h+1)*K/2)), then walks 128-wide column
-// blocks; the weight A operand is read straight from global (coalesced over n, L1/L2 hits).
+// MFMA rows = output columns n, MFMA columns = rows m.  A workgroup owns one 128-wide column
+// block: it stages w[:, n0:n0+128] once into LDS in A-fragment order ([row tile][4 k-steps][lane][4],
+// one conflict-free ds_read_b128 per 4 MFMAs), then its 4 waves walk 32-row tiles keeping their x
+// rows in registers (lane (m,h) holds k in [h*K/2, (h+1)*K/2)).
 // models.py:110-120,128-130 and the hoisted modules.py:216-228.
 // --------------------------------------------------------------------------------------
 template <int KH4>  // K/2 in units of 4 floats (K = 8*KH4)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y, int M,
                                                      int K, int Nout, int relu) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float lds[4 * KH4 * 64 * 4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int m = (blockIdx.x * 4 + wave) * 32 + j;
-    const bool mvalid = m < M;
     const int kh = K / 2;
-    float xb[KH4 * 4];
-#pragma unroll
-    for (int g = 0; g < KH4; ++g) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (mvalid && 4 * g < kh) v = *reinterpret_cast<const f32x4*>(x + (size_t)m * K + h * kh + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xb[4 * g + e] = v[e];
+    const int n0 = blockIdx.y * 128;
+    // stage the weight block: element (k, n0 + c) -> fragment slot of lane (c&31, k/kh), k-step k%kh
+    for (int idx = tid; idx < K * 128; idx += 256) {
+        const int k = idx >> 7, c = idx & 127;
+        const float v = (n0 + c < Nout) ? w[(size_t)k * Nout + n0 + c] : 0.f;
+        const int hh = k / kh, ks = k - hh * kh;
+        lds[(((c >> 5) * KH4 + (ks >> 2)) * 64 + hh * 32 + (c & 31)) * 4 + (ks & 3)] = v;
     }
-    for (int n0 = blockIdx.y * 128; n0 < Nout; n0 += gridDim.y * 128) {
+    __syncthreads();
+    const int row_tiles = (M + 31) / 32;
+    for (int rt = blockIdx.x * 4 + wave; rt < row_tiles; rt += gridDim.x * 4) {
+        const int m = rt * 32 + j;
+        const bool mvalid = m < M;
+        const int mc = mvalid ? m : M - 1;
+        float xb[KH4 * 4];
+#pragma unroll
+        for (int g = 0; g < KH4; ++g) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (4 * g < kh) v = *reinterpret_cast<const f32x4*>(x + (size_t)mc * K + h * kh + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[4 * g + e] = v[e];
+        }
         f32x16 acc[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -86,15 +100,27 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
                 const int n = n0 + chan_of(it, r, h);
                 acc[it][r] = (bias && n < Nout) ? bias[n] : 0.f;
             }
+        f32x4 a[4];
 #pragma unroll
-        for (int ks = 0; ks < KH4 * 4; ++ks) {
-            if (ks < kh) {
-                const float* wr = w + (size_t)(h * kh + ks) * Nout + n0 + j;
+        for (int it = 0; it < 4; ++it) a[it] = *reinterpret_cast<const f32x4*>(&lds[((it * KH4) * 64 + lane) * 4]);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const float a = (n0 + 32 * it + j < Nout) ? wr[32 * it] : 0.f;
-                    acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[ks], acc[it], 0, 0, 0);
+        for (int g = 0; g < KH4; ++g) {
+            if (4 * g < kh) {
+                f32x4 nx[4] = {a[0], a[1], a[2], a[3]};
+                if (g + 1 < KH4) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        nx[it] = *reinterpret_cast<const f32x4*>(&lds[((it * KH4 + g + 1) * 64 + lane) * 4]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it][e], xb[4 * g + e], acc[it], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) a[it] = nx[it];
             }
         }
         if (mvalid) {
@@ -235,9 +261,12 @@ int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y, 
     PWV_CHECK_ARG(Nout >= 4 && Nout % 4 == 0, "pwv_linear_f32: Nout must be a multiple of 4, got %d", Nout);
     if (M == 0) return PWV_OK;
     const int kh = K / 2;   // floats per lane half, loaded as float4 chunks
-    const unsigned gx = (unsigned)((M + 127) / 128);
-    unsigned gy = (unsigned)((Nout + 127) / 128);
-    if (gy > 64) gy = 64;
+    // one workgroup per (row chunk, 128-column block); ~4 workgroups per CU overall
+    const unsigned gy = (unsigned)((Nout + 127) / 128);
+    unsigned gx = (unsigned)((M + 127) / 128);
+    const unsigned cap = (1024u + gy - 1) / gy;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
     dim3 grid(gx, gy), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (kh <= 32)

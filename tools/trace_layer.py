@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Phase timeline of the f16x3 layer kernel: builds a -DPWV_TRACE copy of the library in /tmp, runs one
+launch and prints, per wave of workgroups 0/1, the s_memtime deltas between phase stamps.
+stamps: 0 unit start | 1 loads issued | 2 loads landed | 3 split+acc init done | 4 GEMM1 pair0 done
+        5 GEMM1 pair1 (+gate pair0) done | 6 GEMM2 (+gate pair1) done | 7 stores issued"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from pwv_amd import _lib  # noqa: E402
+
+so = '/tmp/libpwv_trace.so'
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-DPWV_TRACE',
+       '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'parallel-wavenet-vocoder_amd', 'csrc'), '-o', so] + _lib.CSRC
+subprocess.check_call(cmd)
+_lib.LIB_PATH = so
+lib = _lib.lib()
+dev = torch.device('cuda', 0)
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 160000
+G = 2
+trace = torch.zeros(2 * 8 * 8 * 16, dtype=torch.int64, device=dev)
+os.environ['PWV_TRACE_PTR'] = str(trace.data_ptr())
+s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+nf = lib.pwv_layer_packed_floats(0, 0)
+xs = [[torch.randn(rows, 64, device=dev) for _ in range(2)] for _ in range(G)]
+packed = [torch.randn(nf, device=dev) * 0.05 for _ in range(G)]
+proj = [torch.randn(128, device=dev) * 0.1 for _ in range(G)]
+a = _lib.LayerArgs()
+a.G, a.proj_row_stride, a.N, a.T, a.dilation, a.precision, a.skip_init = G, 128, 1, rows, 64, 1, 1
+a.out_mode = _lib.OUT_RESIDUAL
+for g in range(G):
+    a.x_in[g], a.x_out[g] = xs[g][0].data_ptr(), xs[g][1].data_ptr()
+    a.packed[g], a.proj[g] = packed[g].data_ptr(), proj[g].data_ptr()
+for _ in range(3):
+    _lib.check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s))
+torch.cuda.synchronize()
+t = trace.cpu().numpy().reshape(2, 8, 8, 16)
+for b in range(2):
+    t0 = t[b][t[b] > 0].min()
+    for w in range(8):
+        print('wg %d wave %d' % (b, w))
+        for u in range(8):
+            st = t[b, w, u, :8]
+            if st[0] == 0:
+                continue
+            d = [int(st[i + 1] - st[i]) for i in range(7)]
+            print('   unit %d  start %7d | issue %5d wait %6d split %5d g1p0 %5d g1p1 %5d g2 %5d store %5d | total %6d' % (
+                u, st[0] - t0, *d, st[7] - st[0]))
