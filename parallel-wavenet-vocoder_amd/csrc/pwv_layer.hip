@@ -135,12 +135,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
     const int nwg = gridDim.x / p.G;
     int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
 
-    {   // one layer's weights -> LDS (packed order == LDS order)
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = tid; i < kLds / 4; i += 64 * WAVES) dst[i] = src[i];
-        if (tid == 0) *unit_counter = 0;
-    }
+    fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
+    if (tid == 0) *unit_counter = 0;
     __syncthreads();
 
     constexpr int kAS = kLayerBase;
@@ -341,12 +337,7 @@ __global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
     const int Q = p.Q;
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        const int n4 = head_floats(Q) / 4;
-        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-    }
+    fill_lds<head_floats(kMaxQ) / 4, 256>(lds, p.packed[net], tid);   // buffers are sized for kMaxQ
     __syncthreads();
 
     auto no_extra = [](int) {};
@@ -437,7 +428,7 @@ __global__ void pack_layer_kernel(const float* filter, const float* gate, const 
         const int ks = ks4 * 4 + e, tap = ks >> 5, r = ks & 31, h = lane >> 5;
         const int cin = 8 * (r >> 2) + 4 * h + (r & 3);
         const int oc = 32 * it + (lane & 31);
-        v = oc < 64 ? filter[(tap * 64 + cin) * 64 + oc] : gate[(tap * 64 + cin) * 64 + oc - 64];
+        v = oc < 64 ? kFScale * filter[(tap * 64 + cin) * 64 + oc] : kGScale * gate[(tap * 64 + cin) * 64 + oc - 64];
     } else if ((i -= kA1Size) < kA2Size) {
         const int e = i & 3, lane = (i >> 2) & 63, ks4 = (i >> 8) & 7, it = i >> 11;
         const int ks = ks4 * 4 + e, h = lane >> 5;
@@ -472,7 +463,7 @@ __global__ void pack_layer_kernel(const float* filter, const float* gate, const 
             const int r = ks4 * 4 + e, h = lane >> 5;
             const int ci = 8 * (r >> 2) + 4 * h + (r & 3);
             const int oc = 32 * it + (lane & 31);
-            v = oc < 64 ? gc_filter[ci * 64 + oc] : gc_gate[ci * 64 + oc - 64];
+            v = oc < 64 ? kFScale * gc_filter[ci * 64 + oc] : kGScale * gc_gate[ci * 64 + oc - 64];
         }
     }
     out[idx] = v;
@@ -541,7 +532,10 @@ size_t pwv_layer_packed_floats(int with_skip, int cond_channels) {
     return (size_t)layer_floats(with_skip != 0, cond_channels > 0);
 }
 
-size_t pwv_head_packed_floats(int Q) { return (size_t)head_floats(Q); }
+size_t pwv_head_packed_floats(int Q) {
+    (void)Q;   // one size for every Q <= kMaxQ: the kernels copy a fixed-size block into LDS
+    return (size_t)head_floats(kMaxQ);
+}
 
 int pwv_proj_column_map(int* map128) {
     if (!map128) return set_error(PWV_EINVAL, "map128 is NULL");

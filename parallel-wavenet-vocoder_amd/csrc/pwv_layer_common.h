@@ -65,15 +65,40 @@ struct HeadParams {
     int G, N, T, Q;
 };
 
-__device__ __forceinline__ float gate_act(float f, float g) {
-    // tanh(f) * sigmoid(g) = (1 - e^-2f) / ((1 + e^-2f)(1 + e^-g)); one v_rcp, two v_exp.
-    // clamps keep the product of the denominators finite; tanh(+-20) == +-1 in fp32,
-    // sigmoid(-40) = 4e-18.
-    f = fminf(fmaxf(f, -20.f), 20.f);
-    g = fminf(fmaxf(g, -40.f), 40.f);
-    const float e1 = __builtin_amdgcn_exp2f(f * -2.8853900817779268f);
-    const float e2 = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+// The packed filter / gate weights, the per-sample condition weights and the projection P are
+// pre-multiplied by -2*log2(e) / -log2(e), so the GEMM directly yields the exp2 arguments
+//     Fs = -2*log2(e) * F,   Gs = -log2(e) * G
+// and tanh(F)*sigmoid(G) = (1 - 2^Fs) / ((1 + 2^Fs)(1 + 2^Gs)): two v_exp, one v_rcp, no scale
+// multiplies.  Only the upper side needs a clamp (2^57.7 squared stays finite; 2^-inf = 0 is fine):
+// tanh saturates to +-1 in fp32 beyond |F| = 20 (Fs = -+57.7), sigmoid(-40) = 4e-18.
+constexpr float kFScale = -2.8853900817779268f;
+constexpr float kGScale = -1.4426950408889634f;
+__device__ __forceinline__ float gate_act(float fs, float gs) {
+    fs = __builtin_amdgcn_fmed3f(fs, -__builtin_inff(), 57.7f);
+    gs = __builtin_amdgcn_fmed3f(gs, -__builtin_inff(), 57.7f);
+    const float e1 = __builtin_amdgcn_exp2f(fs);
+    const float e2 = __builtin_amdgcn_exp2f(gs);
     return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
+}
+
+// One layer's / head's packed weights -> LDS (packed order == LDS order).  All loads of a thread are
+// issued before the first LDS write so the copy costs one memory round trip, not one per chunk.
+template <int N4, int THREADS>
+__device__ __forceinline__ void fill_lds(float* lds, const float* __restrict__ packed, int tid) {
+    constexpr int ITERS = (N4 + THREADS - 1) / THREADS;
+    const f32x4* src = reinterpret_cast<const f32x4*>(packed);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    f32x4 v[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int idx = tid + i * THREADS;
+        v[i] = src[idx < N4 ? idx : N4 - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int idx = tid + i * THREADS;
+        if (idx < N4) dst[idx] = v[i];
+    }
 }
 
 // lane (t,h) loads its NCH 16-byte chunks (float offsets 8g + 4h) of one channels-last row.

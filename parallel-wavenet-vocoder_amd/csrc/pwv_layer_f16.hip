@@ -106,13 +106,15 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
     int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = tid; i < kLds / 4; i += 64 * WAVES) dst[i] = src[i];
-        if (tid == 0) *unit_counter = 0;
-    }
+#ifdef PWV_TRACE
+    if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
+    fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
+    if (tid == 0) *unit_counter = 0;
     __syncthreads();
+#ifdef PWV_TRACE
+    if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
 
     constexpr int kAS = kLayerBase;
     constexpr int kBS = kAS + kASSize;
@@ -135,9 +137,24 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
     auto no_extra = [](int) {};
 
+    // x[t-d] / x[t] rows of one unit -> registers (clamped addresses, zeros left of the utterance start)
+    auto load_x = [&](int unit, float (&xb)[32], float (&xc)[32]) {
+        const int row = unit * 32 + (lane & 31);
+        const int rc = row < rows ? row : rows - 1;
+        const int t = rc % p.T;
+        const bool has_prev = t >= p.dilation;
+        const float* xrow = p.x_in[net] + (size_t)rc * 64;
+        load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
+        load_row<8>(xrow, h, true, xc);
+    };
+
     int tr_unit = -1;
     (void)tr_unit;
-    for (int unit = grab(); unit < u_end; unit = grab()) {
+    int unit = grab();
+    float rxb[32], rxc[32];      // raw rows of the current unit (prefetched during the previous unit's GEMM2)
+    load_x(unit, rxb, rxc);
+    while (unit < u_end) {
+        const int next = grab();
         ++tr_unit;
         PWV_STAMP(0);
         const int row = unit * 32 + (lane & 31);
@@ -145,40 +162,8 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         const int rc = valid ? row : rows - 1;
         const int n = rc / p.T;
         const int t = rc - n * p.T;
-        const bool has_prev = t >= p.dilation;
-        const float* xrow = p.x_in[net] + (size_t)rc * 64;
 
-        f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
-        float xc[32];
-        {
-            float xb[32];
-            load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
-            load_row<8>(xrow, h, true, xc);
-#ifdef PWV_TRACE
-            PWV_STAMP(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PWV_STAMP(2);
-#endif
-            split8<0>(xb, bh[0], bl[0]);
-            split8<8>(xb, bh[1], bl[1]);
-            split8<16>(xb, bh[2], bl[2]);
-            split8<24>(xb, bh[3], bl[3]);
-            split8<0>(xc, bh[4], bl[4]);
-            split8<8>(xc, bh[5], bl[5]);
-            split8<16>(xc, bh[6], bl[6]);
-            split8<24>(xc, bh[7], bl[7]);
-        }
-        f16x8 ch[5], cl[5];      // per-sample condition, K = 80
-        if constexpr (COND) {
-            float cd[40];
-            load_row<10>(p.cond + (size_t)rc * kCondC, h, true, cd);
-            split8<0>(cd, ch[0], cl[0]);
-            split8<8>(cd, ch[1], cl[1]);
-            split8<16>(cd, ch[2], cl[2]);
-            split8<24>(cd, ch[3], cl[3]);
-            split8<32>(cd, ch[4], cl[4]);
-        }
-        // accumulators start at P[frame(t)]
+        // accumulators start at P[frame(t)] (issued first: lands while x is being split)
         f32x16 acc[4];
         {
             int prow = 0;
@@ -193,6 +178,30 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                     for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                 }
         }
+        f16x8 ch[5], cl[5];      // per-sample condition, K = 80
+        if constexpr (COND) {
+            float cd[40];
+            load_row<10>(p.cond + (size_t)rc * kCondC, h, true, cd);
+            split8<0>(cd, ch[0], cl[0]);
+            split8<8>(cd, ch[1], cl[1]);
+            split8<16>(cd, ch[2], cl[2]);
+            split8<24>(cd, ch[3], cl[3]);
+            split8<32>(cd, ch[4], cl[4]);
+        }
+        PWV_STAMP(1);
+#ifdef PWV_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PWV_STAMP(2);
+        f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
+        float xc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) xc[i] = rxc[i];
+        split8<0>(rxb, bh[0], bl[0]);
+        split8<8>(rxb, bh[1], bl[1]);
+        split8<16>(rxb, bh[2], bl[2]);
+        split8<24>(rxb, bh[3], bl[3]);
+        // x[t] (k-steps 4..7) is split under the first four MFMA groups of pair 0
 
         auto bxh = [&](int s) -> f16x8 { return bh[s]; };
         auto bxl = [&](int s) -> f16x8 { return bl[s]; };
@@ -212,10 +221,18 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         } else {
             first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
         }
-        gemm16<8, 2, 0, 2, 4>(A1, lane, acc, ah, al, bxh, bxl, no_extra, [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
-            if constexpr (COND) first_frags<5, 2, 1, 2, 4>(AC, lane, nh, nl);
-            else first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl);
-        });
+        gemm16<8, 2, 0, 2, 4>(
+            A1, lane, acc, ah, al, bxh, bxl,
+            [&](int s) {
+                if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
+                if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
+                if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
+                if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+            },
+            [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
+                if constexpr (COND) first_frags<5, 2, 1, 2, 4>(AC, lane, nh, nl);
+                else first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl);
+            });
         PWV_STAMP(4);
         // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -------------
         if constexpr (COND) {
@@ -245,6 +262,8 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         PWV_STAMP(5);
         float* orow = p.x_out[net] + (size_t)row * 64;
         if constexpr (GATED) {
+            load_x(next, rxb, rxc);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
             if constexpr (SKIP) {
@@ -269,6 +288,10 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bd[e];
                 }
+            // next unit's rows: in flight under GEMM2 + gating + stores (xc is dead from here on)
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
+            load_x(next, rxb, rxc);
+            __builtin_amdgcn_sched_barrier(0);
             gemm16<4, 2, 0, 1, 2>(
                 A2, lane, acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
                 [&](int s) {
@@ -323,7 +346,15 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        unit = next;
     }
+#ifdef PWV_TRACE
+    if (p.trace && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_max(&p.trace[4096 + blockIdx.x * 4 + 2], (long long)__builtin_amdgcn_s_memtime(), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------
@@ -341,12 +372,7 @@ __global__ __launch_bounds__(256) void head_f16x3_kernel(const HeadParams p) {
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
     const int Q = p.Q;
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.packed[net]);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        const int n4 = head_floats(Q) / 4;
-        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-    }
+    fill_lds<head_floats(kMaxQ) / 4, 256>(lds, p.packed[net], tid);   // buffers are sized for kMaxQ
     __syncthreads();
     const f16x8* HAS = reinterpret_cast<const f16x8*>(&lds[kHAS]);
     const f16x8* HA1 = reinterpret_cast<const f16x8*>(&lds[kHA1]);
@@ -473,7 +499,7 @@ __global__ void pack_layer_f16_kernel(const float* filter, const float* gate, co
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int cin = 16 * (s & 3) + 8 * (q >> 2) + 4 * h + (q & 3);
-            w[q] = oc < 64 ? filter[(tap * 64 + cin) * 64 + oc] : gate[(tap * 64 + cin) * 64 + oc - 64];
+            w[q] = oc < 64 ? kFScale * filter[(tap * 64 + cin) * 64 + oc] : kGScale * gate[(tap * 64 + cin) * 64 + oc - 64];
         }
         put_split(&o16[base], comp, w);
         return;
@@ -525,7 +551,7 @@ __global__ void pack_layer_f16_kernel(const float* filter, const float* gate, co
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int ci = 16 * s + 8 * (q >> 2) + 4 * h + (q & 3);
-            w[q] = oc < 64 ? gc_filter[ci * 64 + oc] : gc_gate[ci * 64 + oc - 64];
+            w[q] = oc < 64 ? kFScale * gc_filter[ci * 64 + oc] : kGScale * gc_gate[ci * 64 + oc - 64];
         }
         put_split(&o16[base], comp, w);
     }

@@ -144,6 +144,10 @@ class NetPlan:
         self.packed_layers = torch.empty((L, self.layer_floats), dtype=torch.float32, device=dev)
         s = _stream()
         colmap = torch.tensor(_lib.proj_column_map(), dtype=torch.long, device=dev)
+        # the kernels gate on exp2 arguments: filter columns carry -2*log2(e), gate columns -log2(e)
+        # (csrc/pwv_layer_common.h: kFScale / kGScale; the packed filter/gate weights carry them too)
+        fg_scale = torch.cat([torch.full((64,), -2.8853900817779268), torch.full((64,), -1.4426950408889634)]).to(
+            device=dev, dtype=torch.float32)
         proj_w, proj_b = [], []
         for j in range(L):
             v = net.layer_variables(j, with_cond=cond_mode != 'none')
@@ -158,10 +162,10 @@ class NetPlan:
                 b = torch.cat([v['filter_bias'], v['gate_bias']])
             else:
                 b = torch.zeros(128, dtype=torch.float32, device=dev)
-            proj_b.append(b[colmap])
+            proj_b.append((b * fg_scale)[colmap])
             if cond_mode == 'frames':
                 wfg = torch.cat([v['gc_filter'][0], v['gc_gate'][0]], dim=1)      # [C, 128]
-                proj_w.append(wfg[:, colmap])
+                proj_w.append((wfg * fg_scale)[:, colmap])
         self.proj_b = torch.cat(proj_b).contiguous()                              # [128*L]
         self.proj_w = torch.cat(proj_w, dim=1).contiguous() if proj_w else None   # [C, 128*L]
         hv = net.head_variables()

@@ -33,7 +33,7 @@ def test_packed_sizes_and_column_map(built_lib):
     assert base == 4 * 16 * 64 * 4 + 2 * 8 * 64 * 4 + 64               # filter|gate + dense + dense bias
     assert lib.pwv_layer_packed_floats(1, 0) == base + 8192 + 128     # + skip + skip bias
     assert lib.pwv_layer_packed_floats(0, 80) == base + 10240         # + per-sample cond
-    assert lib.pwv_head_packed_floats(1) == 8192 + 128 + 16384 + 128 + 2 * 64 + 4
+    assert lib.pwv_head_packed_floats(1) == lib.pwv_head_packed_floats(4) == 8192 + 128 + 16384 + 128 + 2 * 4 * 64 + 4
     cmap = _lib.proj_column_map()
     assert sorted(cmap) == list(range(128))                           # a permutation of F|G channels
     # lane half h owns the 16-byte chunks at float offsets 8g + 4h (v_mfma 32x32 C/D layout)

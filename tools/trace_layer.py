@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Phase timeline of the f16x3 layer kernel: builds a -DPWV_TRACE copy of the library in /tmp, runs one
 launch and prints, per wave of workgroups 0/1, the s_memtime deltas between phase stamps.
-stamps: 0 unit start | 1 loads issued | 2 loads landed | 3 split+acc init done | 4 GEMM1 pair0 done
-        5 GEMM1 pair1 (+gate pair0) done | 6 GEMM2 (+gate pair1) done | 7 stores issued"""
+stamps: 0 unit start | 1 P (+cond) loads issued | 2 all loads landed (trace build waits here) | 3 x[t-d] split
+        4 GEMM1 pair0 (+x[t] split) | 5 GEMM1 pair1 (+gate pair0) | 6 next-unit loads issued + GEMM2 (+gate pair1)
+        7 stores issued"""
 import ctypes
 import os
 import subprocess
@@ -23,7 +24,7 @@ lib = _lib.lib()
 dev = torch.device('cuda', 0)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 160000
 G = 2
-trace = torch.zeros(2 * 8 * 8 * 16, dtype=torch.int64, device=dev)
+trace = torch.zeros(4096 + 4 * 1024, dtype=torch.int64, device=dev)
 os.environ['PWV_TRACE_PTR'] = str(trace.data_ptr())
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 nf = lib.pwv_layer_packed_floats(0, 0)
@@ -37,9 +38,21 @@ for g in range(G):
     a.x_in[g], a.x_out[g] = xs[g][0].data_ptr(), xs[g][1].data_ptr()
     a.packed[g], a.proj[g] = packed[g].data_ptr(), proj[g].data_ptr()
 for _ in range(3):
+    trace.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _lib.check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s))
-torch.cuda.synchronize()
-t = trace.cpu().numpy().reshape(2, 8, 8, 16)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+full = trace.cpu().numpy()
+wgt = full[4096:].reshape(-1, 4)
+wgt = wgt[wgt[:, 0] > 0]
+k0, k1 = wgt[:, 0].min(), wgt[:, 2].max()
+print('kernel: event time %.1f us | first wave start -> last wave end %d ticks (%.2f ticks/ns if they were equal)' % (ms * 1e3, k1 - k0, (k1 - k0) / (ms * 1e6)))
+print('   WG start spread %d ticks; LDS fill mean %d ticks (max %d); WG end: earliest %d, latest %d (after first start)' % (
+    wgt[:, 0].max() - k0, (wgt[:, 1] - wgt[:, 0]).mean(), (wgt[:, 1] - wgt[:, 0]).max(), wgt[:, 2].min() - k0, k1 - k0))
+t = full[:2048].reshape(2, 8, 8, 16)
 for b in range(2):
     t0 = t[b][t[b] > 0].min()
     for w in range(8):
@@ -49,5 +62,5 @@ for b in range(2):
             if st[0] == 0:
                 continue
             d = [int(st[i + 1] - st[i]) for i in range(7)]
-            print('   unit %d  start %7d | issue %5d wait %6d split %5d g1p0 %5d g1p1 %5d g2 %5d store %5d | total %6d' % (
+            print('   unit %d  start %7d | Pissue %5d wait %6d splitb %5d g1p0 %5d g1p1 %5d g2 %5d store %5d | total %6d' % (
                 u, st[0] - t0, *d, st[7] - st[0]))
