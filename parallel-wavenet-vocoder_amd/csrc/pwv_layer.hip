@@ -53,7 +53,7 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
     load_row<8>(xrow, h, true, r.xc);
     load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, r.xb);
     int prow = 0;
-    if (p.cond_hop > 0) prow = n * p.cond_frames + (t + p.cond_offset) / p.cond_hop;
+    if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
     load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.pj);
     if constexpr (COND) load_row<10>(p.cond + (size_t)rc * kCondC, h, true, r.cd);
     if constexpr (SKIP) {
@@ -615,6 +615,8 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     lp.cond_offset = a->cond_offset;
     lp.cond_frames = a->cond_frames;
     lp.skip_init = a->skip_init;
+    make_magic((unsigned)a->T, lp.T_magic, lp.T_shift);
+    make_magic((unsigned)(a->cond_hop > 0 ? a->cond_hop : 1), lp.hop_magic, lp.hop_shift);
     lp.trace = nullptr;
 #ifdef PWV_TRACE
     { const char* e = getenv("PWV_TRACE_PTR"); if (e) lp.trace = (long long*)strtoull(e, nullptr, 0); }

@@ -44,8 +44,42 @@ struct LayerParams {
     int G, N, T, dilation;
     int cond_hop, cond_offset, cond_frames;
     int skip_init;
+    unsigned T_magic, T_shift;      // n / T  == umulhi(n, T_magic) >> T_shift   (T_magic == 0: T == 1)
+    unsigned hop_magic, hop_shift;  // same for cond_hop
     long long* trace;   // debug builds only (-DPWV_TRACE): per-wave phase timestamps
 };
+
+// exact n / d for n < 2^31 (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l) / d), shift = l - 1
+inline void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
+    if (d <= 1) { magic = 0; shift = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long k = 31 + l;
+    magic = (unsigned)(((1ull << k) + d - 1) / d);
+    shift = l - 1;
+}
+__device__ __forceinline__ int fast_div(int n, unsigned magic, unsigned shift) {
+    return magic ? (int)(__umulhi((unsigned)n, magic) >> shift) : n;
+}
+
+// (utterance, time) of the 32 rows of a unit: one scalar division per unit when T >= 32
+__device__ __forceinline__ void unit_rows(int unit, int lane, int rows, int N, int T, unsigned T_magic, unsigned T_shift,
+                                          int& row, bool& valid, int& rc, int& n, int& t) {
+    row = unit * 32 + (lane & 31);
+    valid = row < rows;
+    rc = valid ? row : rows - 1;
+    if (T >= 32) {
+        const int row0 = unit * 32;                       // wave-uniform: scalar mul_hi
+        const int n0 = fast_div(row0, T_magic, T_shift);
+        t = row0 - n0 * T + (lane & 31);
+        n = n0;
+        if (t >= T) { t -= T; n += 1; }
+        if (!valid) { n = N - 1; t = T - 1; }
+    } else {
+        n = fast_div(rc, T_magic, T_shift);
+        t = rc - n * T;
+    }
+}
 
 // -DPWV_TRACE: waves of workgroup 0 record s_memtime at phase boundaries (tools/trace_layer.py)
 #ifdef PWV_TRACE
@@ -74,8 +108,9 @@ struct HeadParams {
 constexpr float kFScale = -2.8853900817779268f;
 constexpr float kGScale = -1.4426950408889634f;
 __device__ __forceinline__ float gate_act(float fs, float gs) {
-    fs = __builtin_amdgcn_fmed3f(fs, -__builtin_inff(), 57.7f);
-    gs = __builtin_amdgcn_fmed3f(gs, -__builtin_inff(), 57.7f);
+    // plain v_min_f32 (inline asm: fminf would get a canonicalising v_max in front of it)
+    asm("v_min_f32 %0, 0x4266cccd, %1" : "=v"(fs) : "v"(fs));   // 57.7f
+    asm("v_min_f32 %0, 0x4266cccd, %1" : "=v"(gs) : "v"(gs));
     const float e1 = __builtin_amdgcn_exp2f(fs);
     const float e2 = __builtin_amdgcn_exp2f(gs);
     return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));

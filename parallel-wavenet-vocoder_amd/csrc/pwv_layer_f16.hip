@@ -109,12 +109,9 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #ifdef PWV_TRACE
     if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
 #endif
-    fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
-    if (tid == 0) *unit_counter = 0;
-    __syncthreads();
-#ifdef PWV_TRACE
-    if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-#endif
+    // the first WAVES units are handed out statically (wave w takes unit w) so their rows can be
+    // requested before the weights are staged; the counter then starts at WAVES
+    if (tid == 0) *unit_counter = WAVES;
 
     constexpr int kAS = kLayerBase;
     constexpr int kBS = kAS + kASSize;
@@ -139,35 +136,43 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 
     // x[t-d] / x[t] rows of one unit -> registers (clamped addresses, zeros left of the utterance start)
     auto load_x = [&](int unit, float (&xb)[32], float (&xc)[32]) {
-        const int row = unit * 32 + (lane & 31);
-        const int rc = row < rows ? row : rows - 1;
-        const int t = rc % p.T;
+        int row, rc, n, t;
+        bool valid;
+        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
         const bool has_prev = t >= p.dilation;
         const float* xrow = p.x_in[net] + (size_t)rc * 64;
-        load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
         load_row<8>(xrow, h, true, xc);
+        if (__all(has_prev)) {      // wave-uniform fast path: no per-register select
+            load_row<8>(xrow - (size_t)p.dilation * 64, h, true, xb);
+        } else {
+            load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
+        }
     };
 
     int tr_unit = -1;
     (void)tr_unit;
-    int unit = grab();
+    int unit = u_begin + wave;
     float rxb[32], rxc[32];      // raw rows of the current unit (prefetched during the previous unit's GEMM2)
-    load_x(unit, rxb, rxc);
+    load_x(unit, rxb, rxc);      // in flight while the weights are staged
+    fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
+    __syncthreads();
+#ifdef PWV_TRACE
+    if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
     while (unit < u_end) {
         const int next = grab();
         ++tr_unit;
         PWV_STAMP(0);
-        const int row = unit * 32 + (lane & 31);
-        const bool valid = row < rows;
-        const int rc = valid ? row : rows - 1;
-        const int n = rc / p.T;
-        const int t = rc - n * p.T;
+        int row, rc, n, t;
+        bool valid;
+        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
+        if (next >= u_end) __builtin_amdgcn_s_setprio(2);   // this wave's last unit: do not let it become the tail
 
         // accumulators start at P[frame(t)] (issued first: lands while x is being split)
         f32x16 acc[4];
         {
             int prow = 0;
-            if (p.cond_hop > 0) prow = n * p.cond_frames + (t + p.cond_offset) / p.cond_hop;
+            if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
             const float* pr = p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64;
 #pragma unroll
             for (int it = 0; it < 4; ++it)

@@ -48,10 +48,17 @@ for _ in range(3):
 full = trace.cpu().numpy()
 wgt = full[4096:].reshape(-1, 4)
 wgt = wgt[wgt[:, 0] > 0]
-k0, k1 = wgt[:, 0].min(), wgt[:, 2].max()
-print('kernel: event time %.1f us | first wave start -> last wave end %d ticks (%.2f ticks/ns if they were equal)' % (ms * 1e3, k1 - k0, (k1 - k0) / (ms * 1e6)))
-print('   WG start spread %d ticks; LDS fill mean %d ticks (max %d); WG end: earliest %d, latest %d (after first start)' % (
-    wgt[:, 0].max() - k0, (wgt[:, 1] - wgt[:, 0]).mean(), (wgt[:, 1] - wgt[:, 0]).max(), wgt[:, 2].min() - k0, k1 - k0))
+dur = wgt[:, 2] - wgt[:, 0]          # per-WG: entry -> last wave done (s_memtime is per-XCD: only differences within a WG mean anything)
+fill = wgt[:, 1] - wgt[:, 0]
+print('kernel event time %.1f us; per-WG duration ticks: min %d mean %d max %d; LDS fill mean %d max %d; %d WGs' % (
+    ms * 1e3, dur.min(), dur.mean(), dur.max(), fill.mean(), fill.max(), len(dur)))
+import numpy as np
+print('   if ticks are 100 MHz-independent shader cycles: max WG duration = %.1f us at 2.2 GHz' % (dur.max() / 2.2e3))
+# same-XCD spread: WG ids b, b+8, ... share an XCD (round-robin dispatch): compare their start times
+for x in range(2):
+    sel = wgt[x::8]
+    print('   XCD %d: start spread %d ticks, end spread %d ticks, first start -> last end %d ticks' % (
+        x, sel[:, 0].max() - sel[:, 0].min(), sel[:, 2].max() - sel[:, 2].min(), sel[:, 2].max() - sel[:, 0].min()))
 t = full[:2048].reshape(2, 8, 8, 16)
 for b in range(2):
     t0 = t[b][t[b] > 0].min()
