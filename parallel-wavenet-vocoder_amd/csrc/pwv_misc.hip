@@ -71,12 +71,30 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     const int h = lane >> 5, j = lane & 31;
     const int kh = K / 2;
     const int n0 = blockIdx.y * 128;
-    // stage the weight block: element (k, n0 + c) -> fragment slot of lane (c&31, k/kh), k-step k%kh
-    for (int idx = tid; idx < K * 128; idx += 256) {
-        const int k = idx >> 7, c = idx & 127;
-        const float v = (n0 + c < Nout) ? w[(size_t)k * Nout + n0 + c] : 0.f;
-        const int hh = k / kh, ks = k - hh * kh;
-        lds[(((c >> 5) * KH4 + (ks >> 2)) * 64 + hh * 32 + (c & 31)) * 4 + (ks & 3)] = v;
+    // stage the weight block: element (k, n0 + c) -> fragment slot of lane (c&31, k/kh), k-step k%kh.
+    // Each thread moves float4s (4 consecutive columns of one k row); all loads are issued before the
+    // first LDS write.  Nout % 4 == 0, so a float4 is either fully inside or fully outside.
+    {
+        constexpr int ITERS = (KH4 * 8 * 32 + 255) / 256;      // K*128/4 float4s over 256 threads
+        f32x4 v[ITERS];
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int idx = tid + i * 256;
+            const int k = idx >> 5, c = (idx & 31) * 4;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < K && n0 + c < Nout) v[i] = *reinterpret_cast<const f32x4*>(w + (size_t)k * Nout + n0 + c);
+        }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int idx = tid + i * 256;
+            const int k = idx >> 5, c = (idx & 31) * 4;
+            if (k < K) {
+                const int hh = k / kh, ks = k - hh * kh;
+                float* dst = &lds[(((c >> 5) * KH4 + (ks >> 2)) * 64 + hh * 32 + (c & 31)) * 4 + (ks & 3)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[4 * e] = v[i][e];     // lanes c..c+3 are 4 floats apart
+            }
+        }
     }
     __syncthreads();
     const int row_tiles = (M + 31) / 32;
