@@ -157,20 +157,24 @@ def main():
         step()
     torch.cuda.synchronize()
     log, engine.EVENT_LOG = engine.EVENT_LOG, None
-    res_ms = [e0.elapsed_time(e1) for tag, e0, e1 in log if tag == 'layer_residual']
+    res_ms = [e0.elapsed_time(e1) for tag, e0, e1, g in log if tag == 'layer_residual']
+    nets_per_launch_timed = [g for tag, e0, e1, g in log if tag == 'layer_residual'][0]
     layer_ms = float(np.mean(res_ms))
     rows = utts * length
-    nets_per_launch = 1 if bool(hp.model.get('shared_nets', False)) else 2
+    nets_per_flow = 1 if bool(hp.model.get('shared_nets', False)) else 2
+    nets_per_launch = nets_per_launch_timed
+    # scalar / shifter chains on two streams: `concurrent` launches of this kernel share the chip at any time
+    concurrent = nets_per_flow // nets_per_launch
     flop_per_launch = rows * nets_per_launch * LAYER_FLOP_PER_SAMPLE
     bytes_per_launch = rows * nets_per_launch * LAYER_BYTES_PER_SAMPLE
-    ach_tf = flop_per_launch / (layer_ms * 1e-3) / 1e12
-    ach_gbs = bytes_per_launch / (layer_ms * 1e-3) / 1e9
+    ach_tf = concurrent * flop_per_launch / (layer_ms * 1e-3) / 1e12
+    ach_gbs = concurrent * bytes_per_launch / (layer_ms * 1e-3) / 1e9
 
     if rank == 0:
         total_samples = rows * n_gpus * args.steps
         value = total_samples / elapsed
         n_layers = sum(len(d) for d in hp.model.dilations[:hp.model.n_iaf])
-        n_nets = hp.model.n_iaf * nets_per_launch
+        n_nets = hp.model.n_iaf * nets_per_flow
         result = {
             'metric': 'audio samples/sec, 4-flow IAF generation',
             'value': value,
@@ -191,7 +195,7 @@ def main():
             'config': {
                 'workload': '%s: %d IAF flows, %d WaveNets (%d dilated layers, R=D=64, S=128, W=2), %s conditioning, '
                             '%d utterance(s) x %d samples per GPU (%.1f s @16 kHz; %d mel frames x %d mels, hop %d)'
-                            % (args.case, hp.model.n_iaf, n_nets, n_layers * nets_per_launch, hp.model.cond_upsample_method,
+                            % (args.case, hp.model.n_iaf, n_nets, n_layers * nets_per_flow, hp.model.cond_upsample_method,
                                utts, length, length / 16000.0, t_mel, n_mels, hop),
                 'case': args.case, 'utterances_per_gpu': utts, 'samples_per_utterance': length,
                 'parallelism': 'utterance-sharded x%d (no data-path collective)' % n_gpus,
@@ -199,7 +203,11 @@ def main():
             },
         }
         common = {'avg_launch_ms': layer_ms, 'launches_timed': len(res_ms), 'alg_flop_per_launch': flop_per_launch,
-                  'alg_bytes_per_launch': bytes_per_launch, 'traffic': None}
+                  'alg_bytes_per_launch': bytes_per_launch, 'traffic': None,
+                  'concurrent_launches': concurrent,
+                  'note': 'achieved = concurrent_launches x algorithmic work per launch / avg launch duration: the scalar and '
+                          'shifter chains of a flow run side by side on two HIP streams, each launch on half of the CUs'
+                          if concurrent > 1 else 'one launch covers all nets of the flow'}
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
         # MI355X_MICROARCH.md prescribes) are collected offline and committed under profiles/; quoted here only
         # when they were taken on this exact workload and kernel
@@ -207,8 +215,8 @@ def main():
         if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get('algorithmic_bytes_per_launch') == bytes_per_launch:
-                common['traffic'] = tj['traffic_bytes_per_launch']
+            if tj.get('algorithmic_bytes_per_launch') == bytes_per_launch * concurrent:
+                common['traffic'] = tj['traffic_bytes_per_launch'] / concurrent
                 common['traffic_source'] = 'profiles/r01_b_hbm_traffic.json'
         if args.precision == 'f32':
             # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound

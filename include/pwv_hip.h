@@ -179,6 +179,40 @@ typedef struct pwv_head_args {
 
 int pwv_wavenet_head_f32(const pwv_head_args* args, pwv_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Whole dilated stack + head of G structurally identical nets in one call: the loop of
+ * WaveNet.__call__ (modules.py:138-165) without a host round trip per layer.
+ *   buf0[g] holds the causal layer's output on entry; buf0/buf1 ping-pong through the layers;
+ *   out[g] receives the net output [N,T,Q].
+ * streams[0] only (streams[1] == NULL): every layer is one launch covering all G nets.
+ * Two streams and G == 2: net g's chain runs on streams[g] with `max_workgroups` workgroups per
+ * launch (0 = half of the CUs), launches interleaved -- the two independent chains then hide each
+ * other's launch gaps and tails.  The caller orders the streams against its own work.
+ * ------------------------------------------------------------------------------------- */
+typedef struct pwv_stack_args {
+    int G;
+    int n_layers;
+    const int* dilations;                         /* HOST array [n_layers] */
+    float* buf0[PWV_MAX_NETS];                    /* [N,T,64] */
+    float* buf1[PWV_MAX_NETS];                    /* [N,T,64] */
+    const float* packed_layers[PWV_MAX_NETS];     /* n_layers packed layer buffers, back to back */
+    size_t packed_layer_stride;                   /* floats between consecutive layers */
+    const float* proj[PWV_MAX_NETS];              /* P rows holding all layers: layer j at +128*j */
+    int proj_row_stride;
+    const float* cond;                            /* [N,T,cond_channels] or NULL */
+    int cond_channels;
+    float* skip[PWV_MAX_NETS];                    /* [N,T,128] or NULL (use_skip_connection) */
+    const float* packed_head[PWV_MAX_NETS];
+    float* out[PWV_MAX_NETS];
+    int Q;
+    int N, T;
+    int cond_hop, cond_offset, cond_frames;
+    int precision;
+    int max_workgroups;
+} pwv_stack_args;
+
+int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     'pwv_last_error', 'pwv_version', 'pwv_device_cus', 'pwv_causal_conv_f32', 'pwv_linear_f32',
     'pwv_upsample_repeat_f32', 'pwv_crop_time_f32', 'pwv_logistic_noise_f32', 'pwv_iaf_front_f32',
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
-    'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32',
+    'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
 )
 
 
@@ -63,6 +63,30 @@ class HeadArgs(Structure):
         ('out', c_void_p * PWV_MAX_NETS),
         ('N', c_int), ('T', c_int), ('Q', c_int),
         ('in_mode', c_int),
+        ('precision', c_int),
+        ('max_workgroups', c_int),
+    ]
+
+
+class StackArgs(Structure):
+    _fields_ = [
+        ('G', c_int),
+        ('n_layers', c_int),
+        ('dilations', POINTER(c_int)),
+        ('buf0', c_void_p * PWV_MAX_NETS),
+        ('buf1', c_void_p * PWV_MAX_NETS),
+        ('packed_layers', c_void_p * PWV_MAX_NETS),
+        ('packed_layer_stride', c_size_t),
+        ('proj', c_void_p * PWV_MAX_NETS),
+        ('proj_row_stride', c_int),
+        ('cond', c_void_p),
+        ('cond_channels', c_int),
+        ('skip', c_void_p * PWV_MAX_NETS),
+        ('packed_head', c_void_p * PWV_MAX_NETS),
+        ('out', c_void_p * PWV_MAX_NETS),
+        ('Q', c_int),
+        ('N', c_int), ('T', c_int),
+        ('cond_hop', c_int), ('cond_offset', c_int), ('cond_frames', c_int),
         ('precision', c_int),
         ('max_workgroups', c_int),
     ]
@@ -111,6 +135,7 @@ def _declare(lib):
     lib.pwv_head_packed_floats.argtypes = [c_int]
     lib.pwv_pack_head_f32.argtypes = [f32p] * 6 + [c_int, c_int, f32p, c_void_p]
     lib.pwv_wavenet_head_f32.argtypes = [POINTER(HeadArgs), c_void_p]
+    lib.pwv_wavenet_stack_f32.argtypes = [POINTER(StackArgs), POINTER(c_void_p)]
     for name in EXPORTED_SYMBOLS:      # fails loudly (AttributeError) if a symbol is missing
         getattr(lib, name)
     return lib

@@ -678,4 +678,71 @@ int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
     return PWV_OK;
 }
 
+int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) {
+    PWV_CHECK_ARG(a && streams, "pwv_wavenet_stack_f32: NULL args / stream array");   // streams[0] may be the NULL (default) stream
+    PWV_CHECK_ARG(a->G >= 1 && a->G <= PWV_MAX_NETS, "pwv_wavenet_stack_f32: G=%d out of range", a->G);
+    PWV_CHECK_ARG(a->n_layers >= 1 && a->dilations, "pwv_wavenet_stack_f32: no layers");
+    const bool two = a->G == 2 && streams[1] != nullptr;
+    const int groups = two ? 2 : 1;           // launch groups per layer
+    const int per_group = two ? 1 : a->G;     // nets per launch
+    int wgs = a->max_workgroups;
+    if (two && wgs == 0) {
+        const int cus = device_cus();
+        if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
+        wgs = cus / 2 > 0 ? cus / 2 : 1;
+    }
+    const bool use_skip = a->skip[0] != nullptr;
+    int cur = 0;
+    for (int j = 0; j < a->n_layers; ++j) {
+        const bool last = j == a->n_layers - 1;
+        for (int grp = 0; grp < groups; ++grp) {
+            pwv_layer_args la{};
+            la.G = per_group;
+            for (int i = 0; i < per_group; ++i) {
+                const int g = two ? grp : i;
+                la.x_in[i] = cur ? a->buf1[g] : a->buf0[g];
+                la.x_out[i] = cur ? a->buf0[g] : a->buf1[g];
+                la.packed[i] = a->packed_layers[g] + (size_t)j * a->packed_layer_stride;
+                la.proj[i] = a->proj[g] + (size_t)128 * j;
+                la.skip[i] = use_skip ? a->skip[g] : nullptr;
+            }
+            la.proj_row_stride = a->proj_row_stride;
+            la.cond = a->cond;
+            la.cond_channels = a->cond_channels;
+            la.skip_init = j == 0;
+            la.N = a->N;
+            la.T = a->T;
+            la.dilation = a->dilations[j];
+            la.cond_hop = a->cond_hop;
+            la.cond_offset = a->cond_offset;
+            la.cond_frames = a->cond_frames;
+            la.out_mode = last ? PWV_OUT_GATED : PWV_OUT_RESIDUAL;
+            la.precision = a->precision;
+            la.max_workgroups = wgs;
+            const int rc = pwv_wavenet_layer_f32(&la, streams[grp]);
+            if (rc != PWV_OK) return rc;
+        }
+        cur ^= 1;
+    }
+    for (int grp = 0; grp < groups; ++grp) {
+        pwv_head_args ha{};
+        ha.G = per_group;
+        for (int i = 0; i < per_group; ++i) {
+            const int g = two ? grp : i;
+            ha.in[i] = use_skip ? a->skip[g] : (cur ? a->buf1[g] : a->buf0[g]);
+            ha.packed[i] = a->packed_head[g];
+            ha.out[i] = a->out[g];
+        }
+        ha.N = a->N;
+        ha.T = a->T;
+        ha.Q = a->Q;
+        ha.in_mode = use_skip ? PWV_HEAD_IN_SKIPSUM : PWV_HEAD_IN_GATED;
+        ha.precision = a->precision;
+        ha.max_workgroups = wgs;
+        const int rc = pwv_wavenet_head_f32(&ha, streams[grp]);
+        if (rc != PWV_OK) return rc;
+    }
+    return PWV_OK;
+}
+
 }  // extern "C"

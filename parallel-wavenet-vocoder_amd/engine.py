@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import HeadArgs, LayerArgs, check
+from ._lib import HeadArgs, LayerArgs, StackArgs, check
 
 # 'f32'  : v_mfma_f32_32x32x2_f32, exact fp32 fma chains (157 TFLOP/s class)
 # 'f16x3': 3-term split-fp16 MFMA with fp32 accumulation (w*x ~= wh*xh + wh*xl + wl*xh, ~22-bit
@@ -33,6 +33,20 @@ DEFAULT_PRECISION = os.environ.get('PWV_PRECISION', 'f16x3')
 # When a list, run_nets brackets every fused-layer launch with HIP events recorded on the
 # launch stream and appends (tag, start_event, end_event): bench.py's live kernel timing.
 EVENT_LOG = None
+
+# The scalar and shifter nets of a flow are independent dependency chains.  With TWO_STREAMS each
+# chain gets its own HIP stream and half of the CUs per launch (G=1), so the two chains drift out
+# of phase and one chain's launch gap / cold start / tail is covered by the other's bulk
+# (measured: 48 vs 55 us per layer pair at 160000 samples).  Otherwise both nets share one launch.
+TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
+_side_streams = {}
+
+
+def _net_streams(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    return _side_streams[key]
 
 
 def _stream() -> c_void_p:
@@ -268,53 +282,96 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             check(lib.pwv_causal_conv_f32(_ptr(x), _ptr(p.causal_filter), _ptr(bufs[g][0]), n, t, qin, R,
                                           net0.filter_width, 1, s), 'pwv_causal_conv_f32')
 
+
     use_skip = bool(net0.use_skip_connection)
     skips = [torch.empty((n, t, net0.skip_channels), dtype=torch.float32, device=dev) for _ in nets] if use_skip else None
-
-    # ---- dilated stack ----------------------------------------------------------------------------
-    a = LayerArgs()
-    a.G = G
-    a.proj_row_stride = row_stride
-    a.cond = _ptr(cond_t)
-    a.cond_channels = net0.condition_channels if mode == 'samples' else 0
-    a.N, a.T = n, t
-    a.cond_hop, a.cond_offset, a.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
-    a.precision = prec
-    a.max_workgroups = max_workgroups
-    cur = 0
-    for j, d in enumerate(net0.dilations):
-        last = j == L - 1
-        for g in range(G):
-            a.x_in[g] = bufs[g][cur].data_ptr()
-            a.x_out[g] = bufs[g][cur ^ 1].data_ptr()
-            a.packed[g] = plans[g].packed_layers[j].data_ptr()
-            a.proj[g] = projs[g].data_ptr() + 4 * 128 * j
-            a.skip[g] = skips[g].data_ptr() if use_skip else None
-        a.skip_init = 1 if j == 0 else 0
-        a.dilation = int(d)
-        a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
-        if EVENT_LOG is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s), 'pwv_wavenet_layer_f32')
-            e1.record()
-            EVENT_LOG.append(('layer_gated' if last else 'layer_residual', e0, e1))
-        else:
-            check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s), 'pwv_wavenet_layer_f32')
-        cur ^= 1
-
-    # ---- post-processing head -----------------------------------------------------------------------
     Q = net0.out_channels
     outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
-    h = HeadArgs()
-    h.G = G
-    h.N, h.T, h.Q = n, t, Q
-    h.in_mode = _lib.HEAD_IN_SKIPSUM if use_skip else _lib.HEAD_IN_GATED
-    h.precision = prec
-    h.max_workgroups = max_workgroups
-    for g in range(G):
-        h.in_[g] = skips[g].data_ptr() if use_skip else bufs[g][cur].data_ptr()
-        h.packed[g] = plans[g].packed_head.data_ptr()
-        h.out[g] = outs[g].data_ptr()
-    check(lib.pwv_wavenet_head_f32(ctypes.byref(h), s), 'pwv_wavenet_head_f32')
+
+    def run_chain(group, stream, stream_obj, wgs):
+        """dilated stack (modules.py:138-142) + post-processing head (modules.py:145-165) for the nets in
+        `group` (indices into `nets`), all launches on `stream`."""
+        a = LayerArgs()
+        a.G = len(group)
+        a.proj_row_stride = row_stride
+        a.cond = _ptr(cond_t)
+        a.cond_channels = net0.condition_channels if mode == 'samples' else 0
+        a.N, a.T = n, t
+        a.cond_hop, a.cond_offset, a.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
+        a.precision = prec
+        a.max_workgroups = wgs
+        cur = 0
+        for j, d in enumerate(net0.dilations):
+            last = j == L - 1
+            for i, g in enumerate(group):
+                a.x_in[i] = bufs[g][cur].data_ptr()
+                a.x_out[i] = bufs[g][cur ^ 1].data_ptr()
+                a.packed[i] = plans[g].packed_layers[j].data_ptr()
+                a.proj[i] = projs[g].data_ptr() + 4 * 128 * j
+                a.skip[i] = skips[g].data_ptr() if use_skip else None
+            a.skip_init = 1 if j == 0 else 0
+            a.dilation = int(d)
+            a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
+            if EVENT_LOG is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream_obj)
+                check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), stream), 'pwv_wavenet_layer_f32')
+                e1.record(stream_obj)
+                EVENT_LOG.append(('layer_gated' if last else 'layer_residual', e0, e1, len(group)))
+            else:
+                check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), stream), 'pwv_wavenet_layer_f32')
+            cur ^= 1
+        h = HeadArgs()
+        h.G = len(group)
+        h.N, h.T, h.Q = n, t, Q
+        h.in_mode = _lib.HEAD_IN_SKIPSUM if use_skip else _lib.HEAD_IN_GATED
+        h.precision = prec
+        h.max_workgroups = wgs
+        for i, g in enumerate(group):
+            h.in_[i] = skips[g].data_ptr() if use_skip else bufs[g][cur].data_ptr()
+            h.packed[i] = plans[g].packed_head.data_ptr()
+            h.out[i] = outs[g].data_ptr()
+        check(lib.pwv_wavenet_head_f32(ctypes.byref(h), stream), 'pwv_wavenet_head_f32')
+
+    main = torch.cuda.current_stream()
+    two = G == 2 and TWO_STREAMS and max_workgroups == 0
+    side = _net_streams(dev) if two else None
+    if two:
+        for g in range(2):
+            side[g].wait_stream(main)
+    if EVENT_LOG is not None:
+        # instrumented path (bench.py's live kernel timing): one host call per launch, events on the launch stream
+        if two:
+            half = max(1, lib.pwv_device_cus() // 2)
+            # (chain order here is net 0 then net 1; the production path below interleaves them)
+            for g in range(2):
+                run_chain([g], c_void_p(side[g].cuda_stream), side[g], half)
+        else:
+            run_chain(list(range(G)), s, main, max_workgroups)
+    else:
+        # production path: the whole stack + head in ONE C call (interleaved over the two streams)
+        sa = StackArgs()
+        sa.G, sa.n_layers = G, L
+        dil = (ctypes.c_int * L)(*[int(d) for d in net0.dilations])
+        sa.dilations = dil
+        for g in range(G):
+            sa.buf0[g], sa.buf1[g] = bufs[g][0].data_ptr(), bufs[g][1].data_ptr()
+            sa.packed_layers[g] = plans[g].packed_layers.data_ptr()
+            sa.proj[g] = projs[g].data_ptr()
+            sa.skip[g] = skips[g].data_ptr() if use_skip else None
+            sa.packed_head[g] = plans[g].packed_head.data_ptr()
+            sa.out[g] = outs[g].data_ptr()
+        sa.packed_layer_stride = plans[0].layer_floats
+        sa.proj_row_stride = row_stride
+        sa.cond = _ptr(cond_t)
+        sa.cond_channels = net0.condition_channels if mode == 'samples' else 0
+        sa.Q, sa.N, sa.T = Q, n, t
+        sa.cond_hop, sa.cond_offset, sa.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
+        sa.precision = prec
+        sa.max_workgroups = max_workgroups
+        streams = (c_void_p * 2)(side[0].cuda_stream if two else s.value, side[1].cuda_stream if two else None)
+        check(lib.pwv_wavenet_stack_f32(ctypes.byref(sa), streams), 'pwv_wavenet_stack_f32')
+    if two:
+        for g in range(2):
+            main.wait_stream(side[g])
     return outs
