@@ -97,3 +97,23 @@ def test_batch_of_utterances_matches_single(gpu):
     for i in range(3):
         yi = one(None, mel[i:i + 1].contiguous(), is_training=False, z=z[i:i + 1].contiguous())
         assert torch.equal(yi[0], yb[i])
+
+
+def test_time_sharding_is_bit_exact(gpu):
+    """overlap-and-discard with the chain halo (6142 -> 6160 samples) reproduces the unsharded
+    forward bit for bit on the reference-default model; a halo one hop short of the receptive field does not."""
+    import torch
+    from pwv_amd.hparam import hparam as hp
+    from pwv_amd.timeshard import chain_halo, generate_time_sharded, shard_plan, vocoder_forward_factory
+    L = 48000
+    model, mel, z = _full_model(gpu, L)
+    want = model(None, mel, is_training=False, z=z)
+    halo = chain_halo(hp.model.dilations, hp.model.filter_width, hp.model.n_iaf, hp.signal.hop_length)
+    assert halo == 6160
+    fwd = vocoder_forward_factory(model.store)
+    got = generate_time_sharded(fwd, mel, z, 80, halo, n_shards=3)
+    assert torch.equal(got, want)
+    # per-rank pieces of a 2-GPU run concatenate to the same thing
+    parts = [generate_time_sharded(fwd, mel, z, 80, halo, n_shards=4, shard_ids=ids) for ids in ([0, 1], [2, 3])]
+    assert torch.equal(torch.cat(parts, dim=1), want)
+    assert [p[0] for p in shard_plan(L, 3, halo, 80)] == [0, 16000 - halo, 32000 - halo]

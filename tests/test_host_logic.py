@@ -115,3 +115,18 @@ def test_fused_supported_matrix():
     assert not mk(normalize='in').fused_supported(None)
     assert not mk(C=40).fused_supported(torch.zeros(1, 160, 40))     # per-sample conditioning kernel is 80-channel
     assert mk(C=40).fused_supported(RepeatedCondition(torch.zeros(1, 3, 40), 80, 40, 160))
+
+
+def test_time_shard_plan():
+    from pwv_amd.timeshard import chain_halo, shard_plan
+    d10 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+    assert chain_halo([d10, d10, d10, d10 * 3], 2, 4, 1) == 6142
+    assert chain_halo([d10, d10, d10, d10 * 3], 2, 4, 80) == 6160
+    plan = shard_plan(960000, 8, 6160, 80)
+    assert plan[0] == (0, 0, 120000) and plan[-1][2] == 960000
+    assert all(a % 80 == 0 and b % 80 == 0 and c % 80 == 0 for c, a, b in plan)
+    assert all(plan[i][2] == plan[i + 1][1] for i in range(7))             # outputs tile [0, L)
+    assert all(a - c == min(a, 6160) for c, a, b in plan)
+    assert len(shard_plan(160, 8, 6160, 80)) == 2                            # never more shards than frames
+    with pytest.raises(ValueError):
+        shard_plan(100, 2, 0, 80)
