@@ -5,8 +5,9 @@ follow from the platform, not from the math:
   * no TF graph/session: the forward is one call of IAFVocoder on the GPU (the reference's single
     sess.run, generate.py:68);
   * the checkpoint is read by variable NAME (EMA shadows preferred when hp.train.use_ema,
-    generate.py:55-66) from an .npz of TF-named arrays; with no checkpoint the model runs with
-    random init exactly like the reference ("No checkpoint found", generate.py:65-66);
+    generate.py:55-66) from a TensorFlow V2 checkpoint (tf_checkpoint.py, no TF needed) or an
+    .npz of TF-named arrays; with no checkpoint the model runs with random init exactly like
+    the reference ("No checkpoint found", generate.py:65-66);
   * the result is written as .wav / .npy files into hp.logdir (the reference only writes
     TensorBoard audio summaries, generate.py:71-73);
   * `data_path: 'synthetic'` (bench cases) or a glob of .npy mel files replaces the wav dataset;
@@ -29,7 +30,12 @@ from .variables import reset_default_store
 
 
 def _latest_checkpoint(logdir):
-    """tf.train.latest_checkpoint analogue for .npz checkpoints: newest file in logdir."""
+    """tf.train.latest_checkpoint: the TF V2 checkpoint named by <logdir>/checkpoint (or the newest
+    *.index), else the newest .npz of TF-named arrays."""
+    from .tf_checkpoint import latest_checkpoint
+    tf_ck = latest_checkpoint(logdir)
+    if tf_ck:
+        return tf_ck
     cands = sorted(glob.glob(os.path.join(logdir, '*.npz')), key=os.path.getmtime)
     return cands[-1] if cands else None
 
@@ -88,7 +94,7 @@ def generate(case='default', ckpt=None, debug=False):
     # load model
     ckpt = '{}/{}'.format(logdir, ckpt) if ckpt else (_latest_checkpoint(logdir) if os.path.isdir(logdir) else None)
     if ckpt:
-        n = store.load_npz(ckpt, use_ema=bool(hp.train.use_ema))
+        n = store.load_checkpoint(ckpt, use_ema=bool(hp.train.use_ema))
         print('Successfully loaded checkpoint {} ({} variables)'.format(ckpt, n))
     else:
         print('No checkpoint found at {}.'.format(logdir))

@@ -84,6 +84,20 @@ class VariableStore:
         with np.load(path) as z:
             return self.load_dict({k: z[k] for k in z.files}, use_ema=use_ema)
 
+    def load_checkpoint(self, path: str, use_ema: bool = False) -> int:
+        """`path` is an .npz of TF-named arrays or a TensorFlow V2 checkpoint prefix (<path>.index +
+        <path>.data-*), read without TensorFlow by tf_checkpoint.py."""
+        import os
+        if path.endswith('.npz') and os.path.exists(path):
+            return self.load_npz(path, use_ema=use_ema)
+        if path.endswith('.index'):
+            path = path[:-len('.index')]
+        if os.path.exists(path + '.index'):
+            from .tf_checkpoint import read_tf_checkpoint
+            keep = lambda n: not (n.endswith('/Adam') or n.endswith('/Adam_1'))
+            return self.load_dict(read_tf_checkpoint(path, name_filter=keep), use_ema=use_ema)
+        raise FileNotFoundError('no checkpoint at %s (.npz or TF V2 .index/.data)' % path)
+
     def save_npz(self, path: str) -> None:
         np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.vars.items()})
 
