@@ -168,7 +168,7 @@ class WaveNet(object):
         scope = self.full_scope
         cur = cc(x, self.causal_filter(), 1)
         if self.normalize:
-            with variable_scope(scope + '/causal_layer'):
+            with variable_scope(scope + '/causal_layer', absolute=True):
                 cur = normalize(cur, self.is_training, self.normalize, store=self.store)
         outputs = []
         for j, d in enumerate(self.dilations):
@@ -183,7 +183,7 @@ class WaveNet(object):
                 g = g + v['gate_bias']
             lscope = scope + '/dilated_stack/layer%d' % j
             if self.normalize:
-                with variable_scope(lscope):
+                with variable_scope(lscope, absolute=True):
                     f = normalize(f, self.is_training, self.normalize, 'normalize_filter', self.store)
                     g = normalize(g, self.is_training, self.normalize, 'normalize_gate', self.store)
             out = torch.tanh(f) * torch.sigmoid(g)
@@ -194,7 +194,7 @@ class WaveNet(object):
                 skip = skip + v['skip_bias']
             dense_out = cur + transformed
             if self.normalize:
-                with variable_scope(lscope):
+                with variable_scope(lscope, absolute=True):
                     skip = normalize(skip, self.is_training, self.normalize, 'normalize_skip_output', self.store)
                     dense_out = normalize(dense_out, self.is_training, self.normalize, 'normalize_dense_output', self.store)
             outputs.append(skip)
@@ -204,14 +204,14 @@ class WaveNet(object):
         t1 = torch.relu(total)
         pscope = scope + '/postprocessing'
         if self.normalize:
-            with variable_scope(pscope):
+            with variable_scope(pscope, absolute=True):
                 t1 = normalize(t1, self.is_training, self.normalize, 'normalize_postprocess1', self.store)
         c1 = cc(t1, hv['postprocess1'], 1)
         if self.use_biases:
             c1 = c1 + hv['postprocess1_bias']
         t2 = torch.relu(c1)
         if self.normalize:
-            with variable_scope(pscope):
+            with variable_scope(pscope, absolute=True):
                 t2 = normalize(t2, self.is_training, self.normalize, 'normalize_postprocess2', self.store)
         c2 = cc(t2, hv['postprocess2'], 1)
         if self.use_biases:

@@ -135,8 +135,18 @@ def reset_default_store(device=None, seed: int = 2) -> VariableStore:
 
 
 @contextlib.contextmanager
-def variable_scope(name: str):
-    """tf.variable_scope: names created inside get the prefix ``<name>/``."""
+def variable_scope(name: str, absolute: bool = False):
+    """tf.variable_scope: names created inside get the prefix ``<name>/``.  ``absolute`` replaces the
+    enclosing scopes instead of nesting in them (re-entering a captured scope, as TF does when a
+    VariableScope object is passed)."""
+    global _scope_stack
+    if absolute:
+        saved, _scope_stack = _scope_stack, [name]
+        try:
+            yield
+        finally:
+            _scope_stack = saved
+        return
     _scope_stack.append(name)
     try:
         yield

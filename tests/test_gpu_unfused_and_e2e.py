@@ -1,0 +1,74 @@
+"""-m gpu: the un-fused GPU path (architectures outside the fused kernels' shape, normalisers: SURVEY.md 8 f-4)
+against the oracle, and generate() end to end (hparams case -> checkpoint by TF name -> forward -> files)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import iaf_oracle as O
+from tests.util import TOL_F32, run_vocoder_hip, set_hparams, small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unfused_other_channel_counts(gpu):
+    """R=32, D=48, S=64, W=3, C=40: composed from pwv_causal_conv_f32 + device elementwise ops."""
+    import torch
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore, variable_scope
+    cfg = O.ModelConfig(dilations=[[1, 2, 5]], n_iaf=1, filter_width=3, residual_channels=32, dilation_channels=48,
+                        skip_channels=64, condition_channels=40, use_skip_connection=True)
+    w = O.init_weights(cfg, seed=8)
+    rng = np.random.RandomState(0)
+    x = rng.randn(2, 100, 1).astype(np.float32)
+    cond = rng.randn(2, 100, 40).astype(np.float32)
+    want = O.wavenet_forward(w, 'iaf_vocoder/iaf0/scalar', x, cond, dilations=[1, 2, 5], use_biases=True,
+                             use_skip_connection=True)
+    store = VariableStore(device=gpu)
+    store.load_dict(w)
+    with variable_scope('iaf_vocoder'), variable_scope('iaf0'):
+        net = WaveNet(2, [1, 2, 5], 3, 32, 48, 64, quantization_channels=1, use_biases=True, condition_channels=40,
+                      use_skip_connection=True, name='scalar', store=store)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    assert not net.fused_supported(t(cond))
+    got = net(t(x), t(cond)).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() <= TOL_F32
+
+
+@pytest.mark.parametrize('method', ['in', 'bn'])
+def test_normaliser_variants(gpu, method):
+    """normalize_wavenet / normalize / normalize_cond = 'in' | 'bn' (modules.py:263-284): identity-initialised
+    gamma/beta/moving stats, so the oracle needs no extra weights."""
+    cfg = small_cfg(normalize_wavenet=method, normalize=method, normalize_cond=method)
+    w = O.init_weights(cfg, seed=2)
+    mel, z = O.synthetic_inputs(2, 320, cfg)
+    want = O.iaf_vocoder_forward(w, mel, z, cfg)
+    got = run_vocoder_hip(cfg, w, mel, z, gpu)
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 5e-5 * max(1.0, np.abs(want).max())
+
+
+def test_generate_end_to_end_with_tf_checkpoint(gpu, tmp_path, monkeypatch):
+    """generate('bench/c1') restores a TensorFlow-format checkpoint by variable name (EMA shadows win), runs
+    the HIP forward and writes wav / npy files; the result equals the oracle run on the EMA weights."""
+    import torch
+    from pwv_amd import tf_checkpoint as T
+    from pwv_amd.generate import generate
+    from pwv_amd.hparam import hparam as hp
+    hp.set_hparam_yaml('bench/c1')
+    cfg = O.ModelConfig.from_hparam(hp)
+    ema = O.init_weights(cfg, seed=21)
+    raw = O.init_weights(cfg, seed=22)
+    ck = dict(raw)
+    ck.update({k + '/ExponentialMovingAverage': v for k, v in ema.items()})
+    logdir = tmp_path / 'logdir'
+    logdir.mkdir()
+    T.write_tf_checkpoint(str(logdir / 'model-100'), ck)
+    (logdir / 'checkpoint').write_text('model_checkpoint_path: "model-100"\n')
+    monkeypatch.setenv('PWV_LOGDIR', str(logdir))
+    monkeypatch.setattr('pwv_amd.engine.logistic_noise_op', lambda shape, device, seed, offset=0: torch.zeros(shape, device=device))
+    pred = generate('bench/c1')
+    assert pred.shape == (1, 16000, 1)
+    mel = (torch.rand((1, 201, 80), generator=torch.Generator().manual_seed(0)) * 2 - 1).numpy()
+    want = O.iaf_vocoder_forward(ema, mel, np.zeros((1, 16000, 1), np.float32), cfg)
+    assert np.abs(pred - want).max() <= TOL_F32
+    assert os.path.exists(logdir / 'pred_0.wav') and os.path.exists(logdir / 'pred_wav.npy')
