@@ -262,9 +262,21 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     L = plans[0].n_layers
 
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
+    main = torch.cuda.current_stream()
+    two = G == 2 and TWO_STREAMS and max_workgroups == 0
+    side = _net_streams(dev) if two else None
     if mode == 'frames':
         f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames_per_utt, -1)
-        projs = [linear_op(f2d, p.proj_w, p.proj_b, relu=False) for p in plans]
+        if two:
+            # net 0's P on the main stream, net 1's on its own stream: its chain then starts one small GEMM
+            # later than net 0's, which keeps the two chains out of phase (they would otherwise run in
+            # lockstep and hit their launch gaps / tails together)
+            projs = [linear_op(f2d, plans[0].proj_w, plans[0].proj_b, relu=False), None]
+            side[1].wait_stream(main)
+            with torch.cuda.stream(side[1]):
+                projs[1] = linear_op(f2d, plans[1].proj_w, plans[1].proj_b, relu=False)
+        else:
+            projs = [linear_op(f2d, p.proj_w, p.proj_b, relu=False) for p in plans]
     else:
         projs = [p.proj_b.reshape(1, -1) for p in plans]
     row_stride = 128 * L
@@ -333,9 +345,6 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             h.out[i] = outs[g].data_ptr()
         check(lib.pwv_wavenet_head_f32(ctypes.byref(h), stream), 'pwv_wavenet_head_f32')
 
-    main = torch.cuda.current_stream()
-    two = G == 2 and TWO_STREAMS and max_workgroups == 0
-    side = _net_streams(dev) if two else None
     if two:
         for g in range(2):
             side[g].wait_stream(main)
