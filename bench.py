@@ -60,27 +60,36 @@ def parse_args():
 
 def cpu_baseline(case_cfg, target_s):
     """Oracle port (torch-CPU fp32 restatement of modules.py:11-259 / models.py:23-136) timed on
-    the host cores on a bounded sample of the same model."""
+    the host cores on a bounded sample of the same model.  oneDNN's small-channel convolutions do not
+    scale to every core of a big host, so a short probe picks the best of a few thread counts first."""
     import torch
     from oracle import iaf_oracle as O
     from oracle.torch_cpu import iaf_vocoder_forward_torch
-    cores = torch.get_num_threads()
     w = O.init_weights(case_cfg, seed=2)
     hop = case_cfg.hop_length
     probe = 50 * hop
     mel, z = O.synthetic_inputs(1, probe, case_cfg)
-    iaf_vocoder_forward_torch(w, mel, z, case_cfg)               # warm-up (oneDNN primitive caches)
-    t0 = time.perf_counter()
-    iaf_vocoder_forward_torch(w, mel, z, case_cfg)
-    rate = probe / (time.perf_counter() - t0)
+    max_threads = torch.get_num_threads()
+    best = (0.0, max_threads)
+    for cores in sorted({max_threads, max(1, max_threads // 2), min(max_threads, 32), min(max_threads, 16)}, reverse=True):
+        torch.set_num_threads(cores)
+        iaf_vocoder_forward_torch(w, mel, z, case_cfg)           # warm-up (oneDNN primitive caches)
+        t0 = time.perf_counter()
+        iaf_vocoder_forward_torch(w, mel, z, case_cfg)
+        rate = probe / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, cores)
+    rate, cores = best
+    torch.set_num_threads(cores)
     length = int(min(160000, max(probe, rate * target_s)) // hop * hop)
     mel, z = O.synthetic_inputs(1, length, case_cfg)
     t0 = time.perf_counter()
     iaf_vocoder_forward_torch(w, mel, z, case_cfg)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(max_threads)
     return {'value': length / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
             'sample': 'same model, 1 utterance x %d samples (%.1f s CPU), torch-CPU fp32 restatement (oracle/torch_cpu.py), '
-                      '%d threads' % (length, dt, cores)}
+                      'best of {%d, %d, 32, 16} threads = %d' % (length, dt, max_threads, max_threads // 2, cores)}
 
 
 def main():
@@ -105,7 +114,10 @@ def main():
     from pwv_amd.hparam import hparam as hp
     from pwv_amd.models import IAFVocoder
     from pwv_amd.variables import VariableStore
-    _lib.build_library()
+    if local_rank == 0:
+        _lib.build_library()          # one builder per node; the others wait (no concurrent hipcc on one .so)
+    if dist is not None:
+        dist.barrier()
 
     hp.set_hparam_yaml(args.case)
     length = args.length or hp.generate.length
