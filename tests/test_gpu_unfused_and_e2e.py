@@ -72,3 +72,34 @@ def test_generate_end_to_end_with_tf_checkpoint(gpu, tmp_path, monkeypatch):
     want = O.iaf_vocoder_forward(ema, mel, np.zeros((1, 16000, 1), np.float32), cfg)
     assert np.abs(pred - want).max() <= TOL_F32
     assert os.path.exists(logdir / 'pred_0.wav') and os.path.exists(logdir / 'pred_wav.npy')
+
+
+def test_generate_sharded_over_rccl_world1(gpu):
+    """The utterance scatter / gather collectives on DEVICE tensors over backend 'nccl' (= RCCL), world size 1
+    (all this box has), with the real HIP forward: result equals the direct batched forward bit for bit."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pwv_amd.distributed import generate_sharded
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    cfg = small_cfg()
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=2))
+    mel, z = O.synthetic_inputs(3, 240, cfg)
+    mel_d, z_d = torch.from_numpy(mel).to(gpu), torch.from_numpy(z).to(gpu)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=gpu)
+    try:
+        def forward(mel_local, z_local):
+            m = IAFVocoder(batch_size=mel_local.shape[0], length=240, store=store)
+            return m(None, mel_local, is_training=False, z=z_local)
+        got = generate_sharded(forward, mel_d, (mel.shape[1], mel.shape[2]), 240, gpu, z=z_d)
+        want = forward(mel_d, z_d)
+        assert got.is_cuda and torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()
