@@ -169,8 +169,10 @@ def main():
         step()
     torch.cuda.synchronize()
     log, engine.EVENT_LOG = engine.EVENT_LOG, None
-    res_ms = [e0.elapsed_time(e1) for tag, e0, e1, g in log if tag == 'layer_residual']
-    nets_per_launch_timed = [g for tag, e0, e1, g in log if tag == 'layer_residual'][0]
+    # each entry: one chain's run of `cnt` back-to-back residual-layer launches between two HIP events
+    chains = [(e0.elapsed_time(e1), cnt, g) for tag, e0, e1, g, cnt in log if tag == 'layer_residual']
+    res_ms = [ms / cnt for ms, cnt, g in chains for _ in range(cnt)]
+    nets_per_launch_timed = chains[0][2]
     layer_ms = float(np.mean(res_ms))
     rows = utts * length
     nets_per_flow = 1 if bool(hp.model.get('shared_nets', False)) else 2

@@ -300,9 +300,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     Q = net0.out_channels
     outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
 
-    def run_chain(group, stream, stream_obj, wgs):
-        """dilated stack (modules.py:138-142) + post-processing head (modules.py:145-165) for the nets in
-        `group` (indices into `nets`), all launches on `stream`."""
+    def launch_layer(group, j, cur, stream, stream_obj, wgs):
         a = LayerArgs()
         a.G = len(group)
         a.proj_row_stride = row_stride
@@ -312,27 +310,19 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
         a.cond_hop, a.cond_offset, a.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
         a.precision = prec
         a.max_workgroups = wgs
-        cur = 0
-        for j, d in enumerate(net0.dilations):
-            last = j == L - 1
-            for i, g in enumerate(group):
-                a.x_in[i] = bufs[g][cur].data_ptr()
-                a.x_out[i] = bufs[g][cur ^ 1].data_ptr()
-                a.packed[i] = plans[g].packed_layers[j].data_ptr()
-                a.proj[i] = projs[g].data_ptr() + 4 * 128 * j
-                a.skip[i] = skips[g].data_ptr() if use_skip else None
-            a.skip_init = 1 if j == 0 else 0
-            a.dilation = int(d)
-            a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
-            if EVENT_LOG is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream_obj)
-                check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), stream), 'pwv_wavenet_layer_f32')
-                e1.record(stream_obj)
-                EVENT_LOG.append(('layer_gated' if last else 'layer_residual', e0, e1, len(group)))
-            else:
-                check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), stream), 'pwv_wavenet_layer_f32')
-            cur ^= 1
+        last = j == L - 1
+        for i, g in enumerate(group):
+            a.x_in[i] = bufs[g][cur].data_ptr()
+            a.x_out[i] = bufs[g][cur ^ 1].data_ptr()
+            a.packed[i] = plans[g].packed_layers[j].data_ptr()
+            a.proj[i] = projs[g].data_ptr() + 4 * 128 * j
+            a.skip[i] = skips[g].data_ptr() if use_skip else None
+        a.skip_init = 1 if j == 0 else 0
+        a.dilation = int(net0.dilations[j])
+        a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
+        check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), stream), 'pwv_wavenet_layer_f32')
+
+    def launch_head(group, cur, stream, wgs):
         h = HeadArgs()
         h.G = len(group)
         h.N, h.T, h.Q = n, t, Q
@@ -345,18 +335,35 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             h.out[i] = outs[g].data_ptr()
         check(lib.pwv_wavenet_head_f32(ctypes.byref(h), stream), 'pwv_wavenet_head_f32')
 
+    def run_instrumented(groups, streams, stream_objs, wgs):
+        """Same launch order as pwv_wavenet_stack_f32 (layer j of every group, then j+1, ..., then the heads),
+        one host call per launch.  Each chain's run of residual-layer launches (all but the last layer) is
+        bracketed by ONE pair of HIP events on its own stream: average launch duration = elapsed / launches,
+        without an event between every two kernels (which would perturb what is being measured)."""
+        cur = 0
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
+        for j in range(L):
+            for k, (grp, st, so) in enumerate(zip(groups, streams, stream_objs)):
+                if j == 0 and L > 1:
+                    evs[k][0].record(so)
+                launch_layer(grp, j, cur, st, so, wgs)
+                if j == L - 2:
+                    evs[k][1].record(so)
+                    EVENT_LOG.append(('layer_residual', evs[k][0], evs[k][1], len(grp), L - 1))
+            cur ^= 1
+        for grp, st in zip(groups, streams):
+            launch_head(grp, cur, st, wgs)
+
     if two:
         for g in range(2):
             side[g].wait_stream(main)
     if EVENT_LOG is not None:
-        # instrumented path (bench.py's live kernel timing): one host call per launch, events on the launch stream
+        # instrumented path (bench.py's live kernel timing)
         if two:
             half = max(1, lib.pwv_device_cus() // 2)
-            # (chain order here is net 0 then net 1; the production path below interleaves them)
-            for g in range(2):
-                run_chain([g], c_void_p(side[g].cuda_stream), side[g], half)
+            run_instrumented([[0], [1]], [c_void_p(side[0].cuda_stream), c_void_p(side[1].cuda_stream)], side[:2], half)
         else:
-            run_chain(list(range(G)), s, main, max_workgroups)
+            run_instrumented([list(range(G))], [s], [main], max_workgroups)
     else:
         # production path: the whole stack + head in ONE C call (interleaved over the two streams)
         sa = StackArgs()
