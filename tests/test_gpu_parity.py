@@ -206,3 +206,46 @@ def test_logistic_noise(gpu):
     assert np.array_equal(z, z2)                       # counter-based: reproducible
     assert np.isfinite(z).all()
     assert abs(z.mean()) < 0.02 and abs(z.var() - np.pi ** 2 / 3) < 0.1   # Logistic(0,1)
+
+
+@pytest.mark.parametrize('precision', PRECS)
+@pytest.mark.parametrize('N,T,dil', [(1, 1, (1, 2)), (1, 7, (1, 2, 4)), (5, 33, (1, 16, 64)), (7, 10, (1, 2, 512)),
+                                     (2, 129, (128, 1))])
+def test_wavenet_tiny_and_ragged(gpu, N, T, dil, precision):
+    """Edge cases: a single sample, T shorter than one 32-row unit, several utterances inside one unit (x[t-d]
+    must not leak across utterance boundaries), dilation > T, T one past a 128-row boundary."""
+    _wavenet_case(gpu, 'none', False, True, 1, T=T, N=N, dil=dil, precision=precision)
+
+
+def test_vocoder_one_frame(gpu):
+    """Shortest legal utterance: one hop (t_mel = 2)."""
+    cfg = small_cfg()
+    weights = O.init_weights(cfg, seed=2)
+    mel, z = O.synthetic_inputs(3, 80, cfg)
+    want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu)
+    assert got.shape == (3, 80, 1) and np.abs(got - want).max() <= TOL_F32
+
+
+def test_misuse_raises(gpu):
+    """Shape errors surface as exceptions (the reference asserts / TF shape errors), never as silent garbage."""
+    import torch
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.modules import causal_conv
+    from pwv_amd.variables import VariableStore
+    cfg = small_cfg()
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    with pytest.raises(ValueError):                       # length must be a multiple of hop (crop at models.py:133)
+        IAFVocoder(2, 100, store=store)(None, torch.zeros(2, 2, 80, device=gpu), False)
+    with pytest.raises(ValueError):                       # wrong t_mel
+        IAFVocoder(2, 160, store=store)(None, torch.zeros(2, 5, 80, device=gpu), False)
+    with pytest.raises(ValueError):                       # z shape
+        IAFVocoder(2, 160, store=store)(None, torch.zeros(2, 3, 80, device=gpu), False, z=torch.zeros(2, 80, 1, device=gpu))
+    with pytest.raises(ValueError):                       # filter Cin mismatch
+        causal_conv(torch.zeros(1, 8, 4, device=gpu), torch.zeros(2, 5, 4, device=gpu), 1)
+    hp = set_hparams(cfg)
+    hp.signal.hop_length = 40                             # prod(strides) != hop  (assert at models.py:106)
+    with pytest.raises(AssertionError):
+        IAFVocoder(1, 80, store=store)(None, torch.zeros(1, 3, 80, device=gpu), False)
+    set_hparams(cfg)
