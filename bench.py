@@ -104,6 +104,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
+        # keep stdout to the one JSON line: RCCL's version banner (NCCL_DEBUG=VERSION/INFO) would land there
+        if os.environ.get('NCCL_DEBUG', '').upper() in ('VERSION', 'INFO', ''):
+            os.environ['NCCL_DEBUG'] = 'WARN'
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=dev)       # RCCL over xGMI
@@ -248,7 +251,8 @@ def main():
                                        'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
         if n_gpus == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(ModelConfig.from_hparam(hp), args.cpu_seconds)
-        print(json.dumps(result))
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
