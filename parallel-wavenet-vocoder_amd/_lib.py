@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_ROOT = os.path.dirname(_PKG_DIR)

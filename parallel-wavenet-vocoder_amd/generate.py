@@ -23,7 +23,6 @@ import sys
 import numpy as np
 import torch
 
-from . import engine
 from .hparam import hparam as hp
 from .models import IAFVocoder
 from .variables import reset_default_store

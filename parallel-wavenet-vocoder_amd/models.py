@@ -10,7 +10,6 @@ from __future__ import annotations
 from typing import Optional
 
 import numpy as np
-import torch
 
 from . import engine
 from .engine import RepeatedCondition

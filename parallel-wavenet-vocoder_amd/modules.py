@@ -15,7 +15,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import _lib, engine
+from . import engine
 from .engine import RepeatedCondition
 from .variables import VariableStore, current_scope, get_default_store, variable_scope
 
