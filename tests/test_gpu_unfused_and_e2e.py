@@ -103,3 +103,33 @@ def test_generate_sharded_over_rccl_world1(gpu):
         assert got.is_cuda and torch.equal(got, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_generate_from_wav_files(gpu, tmp_path, monkeypatch):
+    """generate() on a directory of .wav files: data_load.py-style split (last 10 % of the files), wav -> mel
+    front-end, HIP forward, one waveform per file written next to the checkpoint directory."""
+    from scipy.io import wavfile
+    from pwv_amd.generate import generate
+    from pwv_amd.hparam import hparam as hp
+    sr = 16000
+    for i in range(10):
+        t = np.arange(sr + 4000) / sr
+        wav = 0.3 * np.sin(2 * np.pi * (200 + 40 * i) * t) * (t > 0.1)
+        wavfile.write(str(tmp_path / ('a%02d.wav' % i)), sr, (wav * 32767).astype(np.int16))
+    logdir = tmp_path / 'out'
+    monkeypatch.setenv('PWV_LOGDIR', str(logdir))
+    orig = type(hp).set_hparam_yaml
+
+    def patched(self, case, *a, **k):          # what a user's hparams.yaml case would override
+        r = orig(self, case, *a, **k)
+        self.data_path = str(tmp_path / '*.wav')
+        self.generate.length, self.generate.batch_size = 8000, 2
+        self.model.n_iaf, self.model.dilations = 1, [[1, 2, 4, 8]]
+        return r
+
+    monkeypatch.setattr(type(hp), 'set_hparam_yaml', patched)
+    pred = generate('default')
+    assert pred.shape == (2, 8000, 1) and np.isfinite(pred).all()
+    assert (logdir / 'pred_0.wav').exists() and (logdir / 'pred_1.wav').exists()
+    rate, data = wavfile.read(str(logdir / 'pred_0.wav'))
+    assert rate == sr and data.shape == (8000,)
