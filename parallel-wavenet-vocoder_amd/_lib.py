@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int64, c_size_t, c_uin
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_ROOT = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_PKG_DIR, 'libpwv_hip.so')
+LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so')   # PWV_LIB: A/B another build
 CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_misc.hip')]
 
 PWV_MAX_NETS = 2
@@ -95,6 +95,8 @@ class StackArgs(Structure):
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into the in-tree shared library."""
     srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', 'pwv_common.h'), os.path.join(_PKG_DIR, 'csrc', 'pwv_layer_common.h'), os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
+    if os.environ.get('PWV_LIB'):
+        return LIB_PATH            # an explicitly chosen library is never rebuilt
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
             return LIB_PATH

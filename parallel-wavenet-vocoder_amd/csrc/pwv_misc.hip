@@ -216,31 +216,33 @@ struct FrontParams {
 };
 
 __global__ void iaf_front_kernel(const FrontParams p) {
-    const int r4 = p.R / 4;
-    const int per_row = p.G > 0 ? r4 * p.G : 1;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long rows = (long long)p.N * p.T;
+    // 32-bit index math throughout (N*T*per_row < 2^31 is checked by the launcher): a 64-bit division is
+    // emulated with ~100 instructions and made this bandwidth-bound kernel ALU-bound
+    const unsigned r4 = (unsigned)p.R / 4;
+    const unsigned per_row = p.G > 0 ? r4 * (unsigned)p.G : 1u;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned rows = (unsigned)p.N * (unsigned)p.T;
     if (idx >= rows * per_row) return;
-    const long long row = idx / per_row;
-    const int sub = (int)(idx % per_row);
-    const int t = (int)(row % p.T);
-    auto xval = [&](long long rr) -> float {
+    const unsigned row = idx / per_row;
+    const unsigned sub = idx - row * per_row;
+    const unsigned t = row % (unsigned)p.T;
+    auto xval = [&](unsigned rr) -> float {
         const float zv = p.z[rr];
-        return p.s ? fmaf(zv, p.s[rr * p.sb_stride], p.b[rr * p.sb_stride]) : zv;
+        return p.s ? fmaf(zv, p.s[(size_t)rr * p.sb_stride], p.b[(size_t)rr * p.sb_stride]) : zv;
     };
     if (sub == 0 && p.x_out) p.x_out[row] = xval(row);
     if (p.G == 0) return;
-    const int g = sub / r4, c = (sub % r4) * 4;
+    const unsigned g = sub / r4, c = (sub - g * r4) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.W; ++k) {
-        const int shift = p.W - 1 - k;
+        const unsigned shift = (unsigned)(p.W - 1 - k);
         if (shift > t) continue;
         const float xv = xval(row - shift);
         const f32x4 w = *reinterpret_cast<const f32x4*>(p.filt[g] + (size_t)k * p.R + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w[e], acc[e]);
     }
-    *reinterpret_cast<f32x4*>(p.h[g] + row * p.R + c) = acc;
+    *reinterpret_cast<f32x4*>(p.h[g] + (size_t)row * p.R + c) = acc;
 }
 
 static inline unsigned blocks_for(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
@@ -358,6 +360,7 @@ int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_str
         p.h[g] = h[g];
     }
     const long long total = (long long)N * T * (G > 0 ? (R / 4) * G : 1);
+    PWV_CHECK_ARG(total < (1ll << 31), "pwv_iaf_front_f32: N*T*R*G/4 must stay below 2^31");
     hipLaunchKernelGGL(iaf_front_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
