@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--wgs', type=int, default=0)
     ap.add_argument('--dilation', type=int, default=64)
     ap.add_argument('--G', type=int, default=2)
+    ap.add_argument('--zero', action='store_true', help='all-zero activations and weights (power / DVFS probe)')
     ap.add_argument('--precision', type=int, default=0, help='0 = f32, 1 = f16x3')
     args = ap.parse_args()
     _lib.build_library()
@@ -28,9 +29,10 @@ def main():
     G, rows = args.G, args.rows
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     nf = lib.pwv_layer_packed_floats(0, 0)
-    xs = [[torch.randn(rows, 64, device=dev) for _ in range(2)] for _ in range(G)]
-    packed = [torch.randn(nf, device=dev) * 0.05 for _ in range(G)]
-    proj = [torch.randn(128, device=dev) * 0.1 for _ in range(G)]
+    scale = 0.0 if args.zero else 1.0
+    xs = [[torch.randn(rows, 64, device=dev) * scale for _ in range(2)] for _ in range(G)]
+    packed = [torch.randn(nf, device=dev) * 0.05 * scale for _ in range(G)]
+    proj = [torch.randn(128, device=dev) * 0.1 * scale for _ in range(G)]
     a = LayerArgs()
     a.G = G
     a.proj_row_stride = 128
