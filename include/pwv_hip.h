@@ -37,6 +37,12 @@ extern "C" {
 /* arithmetic of the fused layer / head kernels */
 #define PWV_PREC_F32 0       /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains */
 #define PWV_PREC_F16X3 1     /* 3-term split-fp16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+#define PWV_PREC_F16 2       /* BUILD EXTENSION (the reference is fp32 only): fp16 residual stream in HBM,
+                              * one fp16 MFMA product, fp32 accumulate.  Activation buffers (x_in/x_out,
+                              * buf0/buf1, head `in`, `cond`) then hold fp16 tile32 blocks as written by
+                              * pwv_iaf_front_f16 / pwv_cond_to_f16 and are passed through the same
+                              * pointer fields; P, net outputs and the waveform chain stay fp32.
+                              * No skip accumulation.  ~1e-3 of the fp32 result, not 2e-5. */
 
 typedef void* pwv_stream_t;
 
@@ -85,15 +91,42 @@ int pwv_crop_time_f32(const float* in, float* out, int N, int T_in, int C, int T
 int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * "tile32": the layout of every [rows = N*T, C] ACTIVATION buffer the fused kernels below read or
+ * write (residual stream C = 64, skip sums C = 128, per-sample condition C = 80).  Rows are stored
+ * in blocks of 32; block u holds rows 32u..32u+31 as [C/4 channel quads][32 rows][4 floats]:
+ *     float index of (row, c) = (row/32)*32*C + (c/4)*128 + (row%32)*4 + c%4
+ * so that a wavefront (32 rows, lane (t,h) owning channel quads 2g+h) moves 1 KB of contiguous
+ * memory per vector load / store.  Buffers hold pwv_tile32_floats(rows, C) floats (whole blocks).
+ * These are scratch buffers between pwv_iaf_front_f32 and pwv_wavenet_head_f32; the converters are
+ * for callers that bring their own channels-last tensors (multi-channel input, per-sample condition).
+ * ------------------------------------------------------------------------------------- */
+size_t pwv_tile32_floats(int64_t rows, int C);
+int pwv_rows_to_tile32_f32(const float* in, float* out, int64_t rows, int C, pwv_stream_t stream);
+int pwv_tile32_to_rows_f32(const float* in, float* out, int64_t rows, int C, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * LinearIAFLayer affine + the next flow's causal layer, fused.
  *   x[r] = z[r]*s[r*sb_stride] + b[r*sb_stride]          modules.py:59   (x = z if s == NULL)
  *   h_g[n,t,:] = sum_k x[n, t-(W-1-k), 0] * filt_g[k,0,:]  modules.py:179-180 (no bias)
  * z [N*T]; s, b strided views of the previous flow's net outputs; x_out [N*T] (may be NULL
- * when s == NULL); for g < G: filt[g] is [W,1,R], h[g] is [N,T,R].  G may be 0 (affine only).
+ * when s == NULL); for g < G: filt[g] is [W,1,R], h[g] is a tile32 buffer of N*T rows x R channels
+ * (see below).  G may be 0 (affine only).
  * ------------------------------------------------------------------------------------- */
 int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_stride,
                       float* x_out, int G, const float* const* filt, float* const* h,
                       int N, int T, int W, int R, pwv_stream_t stream);
+
+/* PWV_PREC_F16 front end: same arithmetic as pwv_iaf_front_f32 (R == 64, G >= 1) but h16[g] is an fp16
+ * tile32 buffer: block u = rows 32u..32u+31 as [8 chunks][32 rows][8 halfs]; chunk s*2+h, half q holds
+ * channel 16s + 8(q>>2) + 4h + (q&3) (the order the MFMA B operand consumes);
+ * pwv_tile32_floats(rows, 64) HALFS. */
+int pwv_iaf_front_f16(const float* z, const float* s, const float* b, int sb_stride,
+                      float* x_out, int G, const float* const* filt, void* const* h16,
+                      int N, int T, int W, int R, pwv_stream_t stream);
+
+/* PWV_PREC_F16: per-sample condition [N,T,80] fp32 channels-last (models.py:110-124) -> fp16 tile32
+ * (10 chunks per row, same channel order), pwv_tile32_floats(rows, 80) halfs */
+int pwv_cond_to_f16(const float* cond, void* out16, int N, int T, int C, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused gated-residual layer: WaveNet._create_dilation_layer          modules.py:185-259
@@ -108,8 +141,8 @@ int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_str
  * P is the frame-rate projection of the condition through gc_filter‖gc_gate plus
  * filter_bias‖gate_bias, in the kernel's column order (pwv_proj_column_map); the row used by
  * sample t of utterance n is  n*cond_frames + (t + cond_offset)/cond_hop  (cond_hop == 0:
- * always row 0, i.e. biases only / no conditioning).  `cond` (per-sample condition
- * [N,T,80], transposed-conv upsampling) is NULL in hoisted mode.
+ * always row 0, i.e. biases only / no conditioning).  `cond` (per-sample condition, 80 channels,
+ * transposed-conv upsampling; tile32) is NULL in hoisted mode.
  * ------------------------------------------------------------------------------------- */
 #define PWV_OUT_RESIDUAL 0
 #define PWV_OUT_GATED 1
@@ -131,14 +164,14 @@ int pwv_proj_column_map(int* map128);
 
 typedef struct pwv_layer_args {
     int G;                                 /* nets in this launch (1 or 2) */
-    const float* x_in[PWV_MAX_NETS];       /* [N,T,64] */
-    float* x_out[PWV_MAX_NETS];            /* [N,T,64] */
+    const float* x_in[PWV_MAX_NETS];       /* tile32, N*T rows x 64 */
+    float* x_out[PWV_MAX_NETS];            /* tile32, N*T rows x 64 */
     const float* packed[PWV_MAX_NETS];     /* pwv_pack_layer_f32 output */
     const float* proj[PWV_MAX_NETS];       /* P rows for THIS layer (128 floats each) */
     int proj_row_stride;                   /* floats between consecutive P rows */
-    const float* cond;                     /* [N,T,cond_channels] or NULL */
+    const float* cond;                     /* tile32, N*T rows x cond_channels, or NULL */
     int cond_channels;                     /* 0 or 80 */
-    float* skip[PWV_MAX_NETS];             /* [N,T,128] accumulators or NULL */
+    float* skip[PWV_MAX_NETS];             /* tile32, N*T rows x 128: accumulators, or NULL */
     int skip_init;                         /* 1: skip = ..., 0: skip += ... */
     int N, T, dilation;
     int cond_hop, cond_offset, cond_frames;
@@ -168,7 +201,7 @@ int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* po
 
 typedef struct pwv_head_args {
     int G;
-    const float* in[PWV_MAX_NETS];         /* [N,T,64] gated o, or [N,T,128] skip sum */
+    const float* in[PWV_MAX_NETS];         /* tile32: gated o (64 channels) or skip sum (128) */
     const float* packed[PWV_MAX_NETS];
     float* out[PWV_MAX_NETS];              /* [N,T,Q] */
     int N, T, Q;
@@ -193,15 +226,15 @@ typedef struct pwv_stack_args {
     int G;
     int n_layers;
     const int* dilations;                         /* HOST array [n_layers] */
-    float* buf0[PWV_MAX_NETS];                    /* [N,T,64] */
-    float* buf1[PWV_MAX_NETS];                    /* [N,T,64] */
+    float* buf0[PWV_MAX_NETS];                    /* tile32, N*T rows x 64 */
+    float* buf1[PWV_MAX_NETS];                    /* tile32, N*T rows x 64 */
     const float* packed_layers[PWV_MAX_NETS];     /* n_layers packed layer buffers, back to back */
     size_t packed_layer_stride;                   /* floats between consecutive layers */
     const float* proj[PWV_MAX_NETS];              /* P rows holding all layers: layer j at +128*j */
     int proj_row_stride;
-    const float* cond;                            /* [N,T,cond_channels] or NULL */
+    const float* cond;                            /* tile32, N*T rows x cond_channels, or NULL */
     int cond_channels;
-    float* skip[PWV_MAX_NETS];                    /* [N,T,128] or NULL (use_skip_connection) */
+    float* skip[PWV_MAX_NETS];                    /* tile32, N*T rows x 128, or NULL (use_skip_connection) */
     const float* packed_head[PWV_MAX_NETS];
     float* out[PWV_MAX_NETS];
     int Q;

@@ -127,17 +127,23 @@ def wavenet_forward(weights: Weights, scope: str, input_batch: np.ndarray,
                     condition_batch: Optional[np.ndarray], dilations: Sequence[int],
                     use_biases: bool, use_skip_connection: bool,
                     normalize_method: Optional[str] = None,
-                    dtype=np.float64, conv=causal_conv_direct) -> np.ndarray:
+                    dtype=np.float64, conv=causal_conv_direct, act_round=None) -> np.ndarray:
     """WaveNet.__call__ (modules.py:129-166) with _create_causal_layer (:174-183) and
     _create_dilation_layer (:185-259).  ``scope`` is the TF variable-scope prefix
-    (e.g. 'iaf_vocoder/iaf0/scalar')."""
+    (e.g. 'iaf_vocoder/iaf0/scalar').
+
+    ``act_round`` (default None = the reference's arithmetic) models the reduced-precision STORAGE of the
+    fp16 build extension (PWV_PREC_F16, no reference counterpart): it is applied wherever that mode keeps an
+    activation as fp16 -- the residual stream after the causal layer and after every layer, the gated output
+    feeding dense / skip, relu(total) feeding postprocess1, and a per-sample condition."""
+    rnd = act_round if act_round is not None else (lambda v: v)
     W = {k: v.astype(dtype) for k, v in weights.items() if k.startswith(scope + '/')}
     g = lambda name: W[scope + '/' + name]
     x = input_batch.astype(dtype)
-    cond = None if condition_batch is None else condition_batch.astype(dtype)
+    cond = None if condition_batch is None else rnd(condition_batch.astype(dtype))
 
     # causal layer: no bias even with use_biases (modules.py:179-183)
-    cur = conv(x, g('causal_layer/filter'), 1)
+    cur = rnd(conv(x, g('causal_layer/filter'), 1))
     if normalize_method:
         cur = normalize(cur, normalize_method, W, scope + '/causal_layer/normalize')
 
@@ -155,13 +161,13 @@ def wavenet_forward(weights: Weights, scope: str, input_batch: np.ndarray,
         if normalize_method:                                              # :230-234
             conv_filter = normalize(conv_filter, normalize_method, W, scope + '/' + p + 'normalize_filter')
             conv_gate = normalize(conv_gate, normalize_method, W, scope + '/' + p + 'normalize_gate')
-        out = np.tanh(conv_filter) * _sigmoid(conv_gate)                  # :236
+        out = rnd(np.tanh(conv_filter) * _sigmoid(conv_gate))             # :236
         transformed = out @ g(p + 'dense')[0]                             # :239-240
         skip_output = out @ g(p + 'skip')[0]                              # :243-244
         if use_biases:                                                    # :246-250
             transformed = transformed + g(p + 'dense_bias')
             skip_output = skip_output + g(p + 'skip_bias')
-        dense_output = cur + transformed                                  # :251
+        dense_output = rnd(cur + transformed)                             # :251
         if normalize_method:                                              # :253-257
             skip_output = normalize(skip_output, normalize_method, W, scope + '/' + p + 'normalize_skip_output')
             dense_output = normalize(dense_output, normalize_method, W, scope + '/' + p + 'normalize_dense_output')
@@ -170,7 +176,7 @@ def wavenet_forward(weights: Weights, scope: str, input_batch: np.ndarray,
 
     pp = 'postprocessing/'
     total = sum(outputs) if use_skip_connection else outputs[-1]          # :147
-    t1 = np.maximum(total, 0)                                             # :148
+    t1 = rnd(np.maximum(total, 0))                                        # :148
     if normalize_method:
         t1 = normalize(t1, normalize_method, W, scope + '/' + pp + 'normalize_postprocess1')
     c1 = t1 @ g(pp + 'postprocess1')[0]                                   # :152-153
@@ -187,23 +193,23 @@ def wavenet_forward(weights: Weights, scope: str, input_batch: np.ndarray,
 
 def linear_iaf(weights: Weights, scope: str, x: np.ndarray, cond: Optional[np.ndarray],
                dilations, use_biases, use_skip_connection, normalize_method=None,
-               dtype=np.float64, conv=causal_conv_direct) -> np.ndarray:
+               dtype=np.float64, conv=causal_conv_direct, act_round=None) -> np.ndarray:
     """LinearIAFLayer.__call__ (modules.py:53-60): out = input*scaler(...) + shifter(...)."""
     kw = dict(dilations=dilations, use_biases=use_biases, use_skip_connection=use_skip_connection,
-              normalize_method=normalize_method, dtype=dtype, conv=conv)
+              normalize_method=normalize_method, dtype=dtype, conv=conv, act_round=act_round)
     scale = wavenet_forward(weights, scope + '/scalar', x, cond, **kw)    # :57
     shift = wavenet_forward(weights, scope + '/shifter', x, cond, **kw)   # :58
     return x.astype(dtype) * scale + shift                                # :59
 
 
 def shared_iaf(weights: Weights, scope: str, x, cond, dilations, use_biases, use_skip_connection,
-               dtype=np.float64, conv=causal_conv_direct) -> np.ndarray:
+               dtype=np.float64, conv=causal_conv_direct, act_round=None) -> np.ndarray:
     """BUILD EXTENSION (BASELINE.json configs[1], "shared mean/var"; no reference code):
     one WaveNet per flow (scope '<iaf>/shared') with 1 input channel and 2 output
     channels; channel 0 = scale, channel 1 = shift; out = x*scale + shift."""
     y = wavenet_forward(weights, scope + '/shared', x, cond, dilations=dilations,
                         use_biases=use_biases, use_skip_connection=use_skip_connection,
-                        dtype=dtype, conv=conv)
+                        dtype=dtype, conv=conv, act_round=act_round)
     return x.astype(dtype) * y[..., 0:1] + y[..., 1:2]
 
 
@@ -367,9 +373,9 @@ def synthetic_inputs(n: int, length: int, cfg: ModelConfig, mel_seed: int = 0, z
 
 
 def iaf_vocoder_forward(weights: Weights, mel: np.ndarray, z: np.ndarray, cfg: ModelConfig,
-                        dtype=np.float64, conv=causal_conv_direct, return_flows: bool = False):
+                        dtype=np.float64, conv=causal_conv_direct, return_flows: bool = False, act_round=None):
     """IAFVocoder.__call__ (models.py:23-78) with the logistic noise ``z`` given explicitly
-    (models.py:32-33 samples it; TF's RNG stream is not reproducible)."""
+    (models.py:32-33 samples it; TF's RNG stream is not reproducible).  ``act_round``: see wavenet_forward."""
     hop = cfg.hop_length
     if cfg.cond_upsample_method == 'transposed_conv':
         cond = upsample_cond_transposed(weights, mel, hop, cfg.strides, cfg.normalize_cond or None, dtype)
@@ -383,7 +389,7 @@ def iaf_vocoder_forward(weights: Weights, mel: np.ndarray, z: np.ndarray, cfg: M
     flows = []
     for i in range(cfg.n_iaf):                                              # models.py:34-70
         kw = dict(dilations=cfg.dilations[i], use_biases=cfg.use_biases,
-                  use_skip_connection=cfg.use_skip_connection, dtype=dtype, conv=conv)
+                  use_skip_connection=cfg.use_skip_connection, dtype=dtype, conv=conv, act_round=act_round)
         if cfg.shared_nets:
             x = shared_iaf(weights, 'iaf_vocoder/iaf%d' % i, x, cond, **kw)
         else:

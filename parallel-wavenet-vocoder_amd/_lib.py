@@ -15,10 +15,10 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int64, c_size_t, c_uin
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_ROOT = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so')   # PWV_LIB: A/B another build
-CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_misc.hip')]
+CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip')]
 
 PWV_MAX_NETS = 2
-PREC_F32, PREC_F16X3 = 0, 1
+PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
 OUT_RESIDUAL, OUT_GATED = 0, 1
 HEAD_IN_GATED, HEAD_IN_SKIPSUM = 0, 1
 
@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     'pwv_upsample_repeat_f32', 'pwv_crop_time_f32', 'pwv_logistic_noise_f32', 'pwv_iaf_front_f32',
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
+    'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
 )
 
 
@@ -128,6 +129,12 @@ def _declare(lib):
     lib.pwv_logistic_noise_f32.argtypes = [f32p, c_int64, c_uint64, c_uint64, c_void_p]
     lib.pwv_iaf_front_f32.argtypes = [f32p, f32p, f32p, c_int, f32p, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                       c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_iaf_front_f16.argtypes = lib.pwv_iaf_front_f32.argtypes
+    lib.pwv_cond_to_f16.argtypes = [f32p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.pwv_tile32_floats.restype = c_size_t
+    lib.pwv_tile32_floats.argtypes = [c_int64, c_int]
+    lib.pwv_rows_to_tile32_f32.argtypes = [f32p, f32p, c_int64, c_int, c_void_p]
+    lib.pwv_tile32_to_rows_f32.argtypes = [f32p, f32p, c_int64, c_int, c_void_p]
     lib.pwv_layer_packed_floats.restype = c_size_t
     lib.pwv_layer_packed_floats.argtypes = [c_int, c_int]
     lib.pwv_pack_layer_f32.argtypes = [f32p] * 8 + [c_int, c_int, c_int, f32p, c_void_p]

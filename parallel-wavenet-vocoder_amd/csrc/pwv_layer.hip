@@ -49,22 +49,21 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
     const int n = rc / p.T;
     const int t = rc - n * p.T;
     const bool has_prev = t >= p.dilation;            // x[t-d] = 0 left of the utterance start
-    const float* xrow = p.x_in[net] + (size_t)rc * 64;
-    load_row<8>(xrow, h, true, r.xc);
-    load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, r.xb);
+    load_tiled<8, 64>(p.x_in[net], rc, h, true, r.xc);
+    load_tiled<8, 64>(p.x_in[net], has_prev ? rc - p.dilation : rc, h, has_prev, r.xb);
     int prow = 0;
     if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
     load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.pj);
-    if constexpr (COND) load_row<10>(p.cond + (size_t)rc * kCondC, h, true, r.cd);
+    if constexpr (COND) load_tiled<10, kCondC>(p.cond, rc, h, true, r.cd);
     if constexpr (SKIP) {
-        // skip row [128]: chunk for (it, q) at float offset 32*it + 8*q + 4*h
+        // skip row [128]: chunk for (it, q) = channel quad 8*it + 2*q + h
         if (skip_load) {
-            const float* srow = p.skip[net] + (size_t)rc * 128;
+            const float* srow = p.skip[net] + tile_off(rc, h, 128);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) r.sk[it * 16 + q * 4 + e] = v[e];
                 }
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        float* orow = p.x_out[net] + (size_t)cur.row * 64;
+        float* orow = p.x_out[net] + tile_off(cur.row, h, 64);
         if constexpr (GATED) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
                 }
             }
         } else {
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
                 for (int g = 0; g < 8; ++g) {
                     const int it = g >> 2, q = g & 3;
                     f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
                 }
             }
         }
@@ -301,13 +300,13 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
             gemm_groups<8, 4, 0, 1>(lds, kAS, lane, accs, a, [&](int ks) -> float { return o[ks]; }, no_extra,
                                     [](f32x4(&)[4]) {});
             if (cur.valid) {
-                float* srow = p.skip[net] + (size_t)cur.row * 128;
+                float* srow = p.skip[net] + tile_off(cur.row, h, 128);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(srow + 32 * it + 8 * q + 4 * h) = v;
+                        *reinterpret_cast<f32x4*>(srow + (8 * it + 2 * q) * 128) = v;
                     }
             }
         }
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
         f32x4 a[4];
         if constexpr (FROM_GATED) {
             float o[32];
-            load_row<8>(p.in[net] + (size_t)(valid ? row : rows - 1) * 64, h, true, o);
+            load_tiled<8, 64>(p.in[net], valid ? row : rows - 1, h, true, o);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -367,12 +366,12 @@ __global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
                                         for (int i = 0; i < 4; ++i) n[i] = frag(lds, kHA1, i, 16, 0, lane);
                                     });
         } else {
-            const float* srow = p.in[net] + (size_t)(valid ? row : rows - 1) * 128;
+            const float* srow = p.in[net] + tile_off(valid ? row : rows - 1, h, 128);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
                 }
@@ -553,8 +552,9 @@ int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dens
     PWV_CHECK_ARG(cond_channels == 0 || cond_channels == kCondC,
                   "pwv_pack_layer_f32: per-sample conditioning supports %d channels, got %d", kCondC, cond_channels);
     PWV_CHECK_ARG(cond_channels == 0 || (gc_filter && gc_gate), "pwv_pack_layer_f32: gc weights missing");
-    PWV_CHECK_ARG(precision == PWV_PREC_F32 || precision == PWV_PREC_F16X3, "pwv_pack_layer_f32: unsupported precision %d", precision);
-    if (precision == PWV_PREC_F16X3)
+    PWV_CHECK_ARG(precision >= PWV_PREC_F32 && precision <= PWV_PREC_F16, "pwv_pack_layer_f32: unsupported precision %d", precision);
+    PWV_CHECK_ARG(precision != PWV_PREC_F16 || !with_skip, "pwv_pack_layer_f32: PWV_PREC_F16 does not support skip accumulation");
+    if (precision != PWV_PREC_F32)   // the fp16 mode reads the `hi` halves of the split-fp16 layout
         return launch_pack_layer_f16x3(filter, gate, dense, dense_bias, skip, skip_bias, gc_filter, gc_gate, with_skip,
                                        cond_channels, packed, (hipStream_t)stream);
     const int total = layer_floats(with_skip != 0, cond_channels > 0);
@@ -569,8 +569,8 @@ int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* po
                       pwv_stream_t stream) {
     PWV_CHECK_ARG(post1 && post2 && packed, "pwv_pack_head_f32: NULL weight pointer");
     PWV_CHECK_ARG(Q >= 1 && Q <= kMaxQ, "pwv_pack_head_f32: Q must be in [1,%d], got %d", kMaxQ, Q);
-    PWV_CHECK_ARG(precision == PWV_PREC_F32 || precision == PWV_PREC_F16X3, "pwv_pack_head_f32: unsupported precision %d", precision);
-    if (precision == PWV_PREC_F16X3)
+    PWV_CHECK_ARG(precision >= PWV_PREC_F32 && precision <= PWV_PREC_F16, "pwv_pack_head_f32: unsupported precision %d", precision);
+    if (precision != PWV_PREC_F32)
         return launch_pack_head_f16x3(skip, skip_bias, post1, post1_bias, post2, post2_bias, Q, packed, (hipStream_t)stream);
     const int total = head_floats(Q);
     hipLaunchKernelGGL(pack_head_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, skip, skip_bias,
@@ -584,7 +584,7 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     PWV_CHECK_ARG(a->G >= 1 && a->G <= PWV_MAX_NETS, "pwv_wavenet_layer_f32: G=%d out of range", a->G);
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1 && a->dilation >= 1, "pwv_wavenet_layer_f32: bad N/T/dilation");
     PWV_CHECK_ARG((long long)a->N * a->T < (1ll << 31) - 256, "pwv_wavenet_layer_f32: N*T too large");
-    PWV_CHECK_ARG(a->precision == PWV_PREC_F32 || a->precision == PWV_PREC_F16X3, "pwv_wavenet_layer_f32: unsupported precision %d", a->precision);
+    PWV_CHECK_ARG(a->precision >= PWV_PREC_F32 && a->precision <= PWV_PREC_F16, "pwv_wavenet_layer_f32: unsupported precision %d", a->precision);
     PWV_CHECK_ARG(a->cond_channels == 0 || a->cond_channels == kCondC,
                   "pwv_wavenet_layer_f32: per-sample conditioning supports %d channels", kCondC);
     PWV_CHECK_ARG((a->cond_channels > 0) == (a->cond != nullptr), "pwv_wavenet_layer_f32: cond / cond_channels mismatch");
@@ -633,6 +633,12 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     const bool cond = a->cond != nullptr, gated = a->out_mode == PWV_OUT_GATED;
     PWV_CHECK_ARG(a->out_mode == PWV_OUT_GATED || a->out_mode == PWV_OUT_RESIDUAL, "pwv_wavenet_layer_f32: bad out_mode");
     if (a->precision == PWV_PREC_F16X3) return launch_layer_f16x3(lp, any_skip, cond, gated, g8, s);
+    if (a->precision == PWV_PREC_F16) {
+        PWV_CHECK_ARG(!any_skip, "pwv_wavenet_layer_f32: PWV_PREC_F16 does not support skip accumulation");
+        // 4-wave workgroups with 40 KB (60 KB with cond) of LDS: several per CU
+        const int want = per_net * (cond ? 2 : 3);
+        return launch_layer_h16(lp, cond, gated, want < nt4 ? want : nt4, s);
+    }
     if (any_skip) {
         if (cond) return gated ? launch_layer<true, true, true>(lp, g4, g8, s) : launch_layer<true, true, false>(lp, g4, g8, s);
         return gated ? launch_layer<true, false, true>(lp, g4, g8, s) : launch_layer<true, false, false>(lp, g4, g8, s);
@@ -647,7 +653,7 @@ int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_head_f32: bad N/T");
     PWV_CHECK_ARG((long long)a->N * a->T < (1ll << 31) - 256, "pwv_wavenet_head_f32: N*T too large");
     PWV_CHECK_ARG(a->Q >= 1 && a->Q <= kMaxQ, "pwv_wavenet_head_f32: Q must be in [1,%d]", kMaxQ);
-    PWV_CHECK_ARG(a->precision == PWV_PREC_F32 || a->precision == PWV_PREC_F16X3, "pwv_wavenet_head_f32: unsupported precision %d", a->precision);
+    PWV_CHECK_ARG(a->precision >= PWV_PREC_F32 && a->precision <= PWV_PREC_F16, "pwv_wavenet_head_f32: unsupported precision %d", a->precision);
     PWV_CHECK_ARG(a->in_mode == PWV_HEAD_IN_GATED || a->in_mode == PWV_HEAD_IN_SKIPSUM, "pwv_wavenet_head_f32: bad in_mode");
     HeadParams hp{};
     for (int g = 0; g < a->G; ++g) {
@@ -666,6 +672,12 @@ int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
     const int ntiles = (int)((rows + 127) / 128);
     int per_net = (a->max_workgroups > 0 ? a->max_workgroups : cus) / a->G;
     if (per_net < 1) per_net = 1;
+    if (a->precision == PWV_PREC_F16) {
+        PWV_CHECK_ARG(a->in_mode == PWV_HEAD_IN_GATED, "pwv_wavenet_head_f32: PWV_PREC_F16 needs in_mode PWV_HEAD_IN_GATED");
+        per_net *= 3;
+        if (per_net > ntiles) per_net = ntiles;
+        return launch_head_h16(hp, per_net * a->G, (hipStream_t)stream);
+    }
     if (per_net > ntiles) per_net = ntiles;
     const int grid = per_net * a->G;
     if (a->precision == PWV_PREC_F16X3)

@@ -108,9 +108,12 @@ struct HeadParams {
 constexpr float kFScale = -2.8853900817779268f;
 constexpr float kGScale = -1.4426950408889634f;
 __device__ __forceinline__ float gate_act(float fs, float gs) {
-    // plain v_min_f32 (inline asm: fminf would get a canonicalising v_max in front of it)
-    asm("v_min_f32 %0, 0x4266cccd, %1" : "=v"(fs) : "v"(fs));   // 57.7f
-    asm("v_min_f32 %0, 0x4266cccd, %1" : "=v"(gs) : "v"(gs));
+    // upper clamp as ONE v_med3_f32 each (fminf would get a canonicalising v_max in front of it).  It must be an
+    // instruction the compiler knows: fs / gs are MFMA results, and the hazard recogniser does not insert the
+    // MFMA-write -> VALU-read wait states in front of inline asm (an asm v_min here read a stale accumulator
+    // register whenever the scheduler placed it right behind the last MFMA).
+    fs = __builtin_amdgcn_fmed3f(fs, -3.0e38f, 57.7f);
+    gs = __builtin_amdgcn_fmed3f(gs, -3.0e38f, 57.7f);
     const float e1 = __builtin_amdgcn_exp2f(fs);
     const float e2 = __builtin_amdgcn_exp2f(gs);
     return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
@@ -133,6 +136,31 @@ __device__ __forceinline__ void fill_lds(float* lds, const float* __restrict__ p
     for (int i = 0; i < ITERS; ++i) {
         const int idx = tid + i * THREADS;
         if (idx < N4) dst[idx] = v[i];
+    }
+}
+
+// ---- "tile32" activation layout ---------------------------------------------------------------------
+// Every [rows, C] activation buffer the fused kernels read or write (residual stream C = 64, skip sums
+// C = 128, per-sample condition C = 80) is stored in blocks of 32 consecutive rows; block u holds rows
+// 32u .. 32u+31 as [C/4 channel quads][32 rows][4 floats].  A wave owns 32 rows and lane (t, h) owns channel
+// quads 2g + h, so each of its vector loads / stores covers 1 KB of CONTIGUOUS memory (32 rows x 16 B for
+// h = 0, then the same for h = 1).  With plain channels-last rows the same instruction touched 32 B in each of
+// 32 cache lines: measured 64 -> 50 us per layer launch at 160000 rows.
+// Buffers are padded to whole blocks: tile32_floats(rows, C).
+__host__ __device__ inline size_t tile32_floats(long long rows, int C) { return (size_t)((rows + 31) / 32) * 32 * C; }
+__device__ __forceinline__ size_t tile_off(int row, int quad, int C) {
+    return (size_t)(row >> 5) * (32 * C) + quad * 128 + (row & 31) * 4;
+}
+// lane (t,h) loads channel quads 2g + h, g < NCH, of row `row` (always a valid row: callers clamp);
+// `keep == false` zeroes the result with v_cndmask instead of branching around the loads.
+template <int NCH, int C>
+__device__ __forceinline__ void load_tiled(const float* __restrict__ base, int row, int h, bool keep, float (&dst)[4 * NCH]) {
+    const float* p0 = base + tile_off(row, h, C);
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p0 + g * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * g + e] = keep ? v[e] : 0.f;
     }
 }
 
@@ -168,5 +196,9 @@ int launch_pack_layer_f16x3(const float* filter, const float* gate, const float*
                             int with_skip, int cond_c, float* out, hipStream_t s);
 int launch_pack_head_f16x3(const float* skip, const float* skip_bias, const float* post1, const float* post1_bias,
                            const float* post2, const float* post2_bias, int Q, float* out, hipStream_t s);
+
+// launchers of the fp16-storage variants (pwv_layer_h16.hip)
+int launch_layer_h16(const LayerParams& lp, bool cond, bool gated, int per_net, hipStream_t s);
+int launch_head_h16(const HeadParams& hp, int grid, hipStream_t s);
 
 }  // namespace pwv

@@ -140,12 +140,11 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         bool valid;
         unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
         const bool has_prev = t >= p.dilation;
-        const float* xrow = p.x_in[net] + (size_t)rc * 64;
-        load_row<8>(xrow, h, true, xc);
+        load_tiled<8, 64>(p.x_in[net], rc, h, true, xc);
         if (__all(has_prev)) {      // wave-uniform fast path: no per-register select
-            load_row<8>(xrow - (size_t)p.dilation * 64, h, true, xb);
+            load_tiled<8, 64>(p.x_in[net], rc - p.dilation, h, true, xb);
         } else {
-            load_row<8>(has_prev ? xrow - (size_t)p.dilation * 64 : xrow, h, has_prev, xb);
+            load_tiled<8, 64>(p.x_in[net], has_prev ? rc - p.dilation : rc, h, has_prev, xb);
         }
     };
 
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         f16x8 ch[5], cl[5];      // per-sample condition, K = 80
         if constexpr (COND) {
             float cd[40];
-            load_row<10>(p.cond + (size_t)rc * kCondC, h, true, cd);
+            load_tiled<10, kCondC>(p.cond, rc, h, true, cd);
             split8<0>(cd, ch[0], cl[0]);
             split8<8>(cd, ch[1], cl[1]);
             split8<16>(cd, ch[2], cl[2]);
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             });
 
         PWV_STAMP(5);
-        float* orow = p.x_out[net] + (size_t)row * 64;
+        float* orow = p.x_out[net] + tile_off(row, h, 64);
         if constexpr (GATED) {
             load_x(next, rxb, rxc);
             __builtin_amdgcn_sched_barrier(0);
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
                 }
             }
         } else {
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 for (int g = 0; g < 8; ++g) {
                     const int it = g >> 2, q = g & 3;
                     f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * h) = v;
+                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
                 }
             }
             PWV_STAMP(7);
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         if constexpr (SKIP) {
             // ---- skip 64 -> 128, accumulated across layers ------------------------------------------
             f32x16 accs[4];
-            float* srow = p.skip[net] + (size_t)rc * 128;
+            float* srow = p.skip[net] + tile_off(rc, h, 128);
             const bool skip_load = !p.skip_init;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kBS + h * 64 + it * 16 + q * 4]);
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (skip_load) v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+                    if (skip_load) v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e] + bs[e];
                 }
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(srow + 32 * it + 8 * q + 4 * h) = v;
+                        *reinterpret_cast<f32x4*>(srow + (8 * it + 2 * q) * 128) = v;
                     }
             }
         }
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(256) void head_f16x3_kernel(const HeadParams p) {
             f16x8 oh[4], ol[4];
             {
                 float o[32];
-                load_row<8>(p.in[net] + (size_t)rc * 64, h, true, o);
+                load_tiled<8, 64>(p.in[net], rc, h, true, o);
                 split8<0>(o, oh[0], ol[0]);
                 split8<8>(o, oh[1], ol[1]);
                 split8<16>(o, oh[2], ol[2]);
@@ -413,12 +412,12 @@ __global__ __launch_bounds__(256) void head_f16x3_kernel(const HeadParams p) {
                                   [&](int s) -> f16x8 { return ol[s]; }, no_extra,
                                   [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 4, 0, 1, 4>(HA1, lane, nh, nl); });
         } else {
-            const float* srow = p.in[net] + (size_t)rc * 128;
+            const float* srow = p.in[net] + tile_off(rc, h, 128);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + 32 * it + 8 * q + 4 * h);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
                 }

@@ -1,0 +1,400 @@
+// fp16 mode ("f16") of the fused layer / head kernels for gfx950: the BUILD EXTENSION named by BASELINE.json
+// config 5 ("fp16"); the reference is fp32 only (models.py:81-82), so this mode has no reference parity --
+// its tolerance is stated against the fp64 oracle (tests/test_gpu_f16.py) and it is never the benchmark default.
+//
+// Same math and launch structure as pwv_layer_f16.hip (reference call sites modules.py:185-259, :145-165) but
+//   * the residual stream lives in HBM as fp16 (128 B per sample instead of 256), tile32-style: block u = rows
+//     32u..32u+31 as [8 chunks][32 rows][8 halfs], chunk s*2 + h holding channels 16s + 8(q>>2) + 4h + (q&3),
+//     q < 8 -- exactly the eight values lane (t, h) feeds to the matrix pipe for k-step s, so ONE 16-byte load
+//     per k-step goes from HBM into the B operand untouched, and each wave-level load is 1 KB contiguous;
+//   * one fp16 product per term (weights = the `hi` halves of the split-fp16 packed buffers, read in place),
+//     fp32 accumulation: 40 MFMAs per 32-sample unit instead of 120;
+//   * ~41 KB of LDS per workgroup (4 waves), several workgroups per CU.
+#include "pwv_layer_common.h"
+
+namespace pwv {
+
+typedef float f32x2h __attribute__((ext_vector_type(2)));
+
+// half offset of chunk (s, h) of flat row `row` in an fp16 tile32 buffer of C channels (C/8 chunks per row)
+__device__ __forceinline__ size_t xoff(int row, int chunk, int C) {
+    return (size_t)(row >> 5) * (32 * C) + (chunk * 32 + (row & 31)) * 8;
+}
+
+// 8 fp32 registers -> one fp16 fragment (round to nearest even)
+template <int OFF, int N>
+__device__ __forceinline__ f16x8 to_h8(const float (&x)[N]) {
+    f16x8 r;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const f32x2h v = {x[OFF + q], x[OFF + q + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        r[q] = h[0];
+        r[q + 1] = h[1];
+    }
+    return r;
+}
+
+// only the `hi` component of a split-fp16 section is staged: NIT*NS*64 16-byte units starting at the section base
+template <int UNITS, int THREADS>
+__device__ __forceinline__ void fill_hi(f16x8* dst, const float* __restrict__ packed_section, int tid) {
+    constexpr int ITERS = (UNITS + THREADS - 1) / THREADS;
+    const f16x8* src = reinterpret_cast<const f16x8*>(packed_section);
+    f16x8 v[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int idx = tid + i * THREADS;
+        v[i] = src[idx < UNITS ? idx : UNITS - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int idx = tid + i * THREADS;
+        if (idx < UNITS) dst[idx] = v[i];
+    }
+}
+
+// GEMM over NS k-steps with NIT row tiles, fragments prefetched one k-step ahead
+template <int NS, int NIT, int NACC, typename BF>
+__device__ __forceinline__ void gemm_h(const f16x8* A, int lane, f32x16 (&acc)[NACC], BF&& bfrag) {
+    f16x8 a[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) a[i] = A[(i * NS + 0) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f16x8 n[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) n[i] = a[i];
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) n[i] = A[(i * NS + s + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 b = bfrag(s);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b, acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) a[i] = n[i];
+    }
+}
+
+// LDS map (16-byte units unless noted): A1 hi [4 it][8 s][64] | A2 hi [2][4][64] | AC hi [4][5][64] | BD 64 floats | counter
+constexpr int kH_A1 = 0;
+constexpr int kH_A2 = kH_A1 + 4 * 8 * 64;      // 2048
+constexpr int kH_AC = kH_A2 + 2 * 4 * 64;      // 2560
+constexpr int kH_END = kH_AC + 4 * 5 * 64;     // 3840 units = 61,440 B (with cond); 40,960 B without
+
+#ifndef PWV_H16_MINWAVES
+#define PWV_H16_MINWAVES 2
+#endif
+template <bool COND, bool GATED>
+__global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const LayerParams p) {
+    constexpr int WAVES = 4;
+    constexpr int kUnits = COND ? kH_END : kH_AC;
+    __shared__ __attribute__((aligned(16))) f16x8 lds[kUnits + 64 / 4 + 1];   // + BD (64 floats) + counter
+    float* bd_lds = reinterpret_cast<float*>(&lds[kUnits]);
+    int* unit_counter = reinterpret_cast<int*>(&lds[kUnits + 16]);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int net = blockIdx.x % p.G;
+    const int wg = blockIdx.x / p.G;
+    const int nwg = gridDim.x / p.G;
+    const float* packed = p.packed[net];
+    // the split-fp16 packed layout keeps [hi | lo] per section; only the hi halves are staged
+    fill_hi<4 * 8 * 64, 256>(&lds[kH_A1], packed + kA1, tid);
+    fill_hi<2 * 4 * 64, 256>(&lds[kH_A2], packed + kA2, tid);
+    if constexpr (COND) fill_hi<4 * 5 * 64, 256>(&lds[kH_AC], packed + kLayerBase, tid);
+    if (tid < 64) bd_lds[tid] = packed[kBD + tid];
+    if (tid == 0) *unit_counter = WAVES;
+    __syncthreads();
+
+    const _Float16* xin = reinterpret_cast<const _Float16*>(p.x_in[net]);
+    _Float16* xout = reinterpret_cast<_Float16*>(p.x_out[net]);
+    const _Float16* cond = reinterpret_cast<const _Float16*>(p.cond);
+    const int rows = p.N * p.T;
+    const int units = (rows + 31) / 32;
+    const int per_wg = (units + nwg - 1) / nwg;
+    const int u_begin = wg * per_wg < units ? wg * per_wg : units;
+    const int u_end = (u_begin + per_wg < units) ? u_begin + per_wg : units;
+    auto grab = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(unit_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return u_begin + __builtin_amdgcn_readfirstlane(v);
+    };
+
+    for (int unit = u_begin + wave; unit < u_end; unit = grab()) {
+        int row, rc, n, t;
+        bool valid;
+        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
+        const bool has_prev = t >= p.dilation;
+        const _Float16* xr = xin + xoff(rc, h, 64);
+        const _Float16* xp = xin + xoff(has_prev ? rc - p.dilation : rc, h, 64);
+        f16x8 b[8];          // k-steps 0..3 = x[t-d], 4..7 = x[t]: straight from HBM into the B operand
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            b[4 + s] = *reinterpret_cast<const f16x8*>(xr + s * 512);
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xp + s * 512);
+            const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            b[s] = has_prev ? v : zero;
+        }
+        f16x8 cb[5];
+        if constexpr (COND) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) cb[s] = *reinterpret_cast<const f16x8*>(cond + xoff(rc, h, kCondC) + s * 512);
+        }
+        f32x16 acc[4];
+        {
+            int prow = 0;
+            if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
+            const float* pr = p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
+                }
+        }
+        if constexpr (COND) gemm_h<5, 4>(&lds[kH_AC], lane, acc, [&](int s) -> f16x8 { return cb[s]; });
+        gemm_h<8, 4>(&lds[kH_A1], lane, acc, [&](int s) -> f16x8 { return b[s]; });
+
+        float o[32];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[tl * 16 + r] = gate_act(acc[tl][r], acc[tl + 2][r]);
+        f16x8 oh[4];
+        oh[0] = to_h8<0>(o);
+        oh[1] = to_h8<8>(o);
+        oh[2] = to_h8<16>(o);
+        oh[3] = to_h8<24>(o);
+
+        _Float16* orow = xout + xoff(row, h, 64);
+        if constexpr (GATED) {
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8*>(orow + s * 512) = oh[s];
+            }
+        } else {
+            // dense 64 -> 64; accumulator starts at x[t] + dense_bias (register r of tile it <-> half q = r&7 of chunk 2it + (r>>3))
+            f32x16 acc2[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc2[it][r] = (float)b[4 + 2 * it + (r >> 3)][r & 7] + bd_lds[h * 32 + it * 16 + r];
+            gemm_h<4, 2>(&lds[kH_A2], lane, acc2, [&](int s) -> f16x8 { return oh[s]; });
+            if (valid) {
+                float y[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) y[i] = acc2[i >> 4][i & 15];
+                *reinterpret_cast<f16x8*>(orow + 0 * 512) = to_h8<0>(y);
+                *reinterpret_cast<f16x8*>(orow + 1 * 512) = to_h8<8>(y);
+                *reinterpret_cast<f16x8*>(orow + 2 * 512) = to_h8<16>(y);
+                *reinterpret_cast<f16x8*>(orow + 3 * 512) = to_h8<24>(y);
+            }
+        }
+    }
+}
+
+// ---- head: o (fp16, permuted) -> skip -> relu -> post1 -> relu -> post2 (fp32 out) ----------------------
+constexpr int kHH_AS = 0;                        // skip hi [4][4][64]
+constexpr int kHH_A1 = kHH_AS + 4 * 4 * 64;      // post1 hi [4][8][64]
+constexpr int kHH_END = kHH_A1 + 4 * 8 * 64;     // 3072 units = 49,152 B
+constexpr int kHH_FLOATS = 128 + 128 + 2 * kMaxQ * 64 + 4;   // skip bias, post1 bias, post2 weights, post2 bias
+
+__global__ __launch_bounds__(256) void head_h16_kernel(const HeadParams p) {
+    __shared__ __attribute__((aligned(16))) f16x8 lds[kHH_END + (kHH_FLOATS + 3) / 4];
+    float* fl = reinterpret_cast<float*>(&lds[kHH_END]);
+    float* bs = fl;
+    float* b1 = fl + 128;
+    float* w2 = fl + 256;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int net = blockIdx.x % p.G;
+    const int wg = blockIdx.x / p.G;
+    const int nwg = gridDim.x / p.G;
+    const int Q = p.Q;
+    const float* packed = p.packed[net];
+    fill_hi<4 * 4 * 64, 256>(&lds[kHH_AS], packed + kHAS, tid);
+    fill_hi<4 * 8 * 64, 256>(&lds[kHH_A1], packed + kHA1, tid);
+    if (tid < 128) {
+        bs[tid] = packed[kHBS + tid];
+        b1[tid] = packed[kHB1 + tid];
+    }
+    for (int i = tid; i < 2 * Q * 64 + 4; i += 256) w2[i] = packed[kHW2 + i];
+    __syncthreads();
+    const _Float16* in = reinterpret_cast<const _Float16*>(p.in[net]);
+    const int rows = p.N * p.T;
+    const int ntiles = (rows + 127) / 128;
+    for (int tile = wg; tile < ntiles; tile += nwg) {
+        const int row = tile * 128 + wave * 32 + (lane & 31);
+        const bool valid = row < rows;
+        const int rc = valid ? row : rows - 1;
+        f16x8 ob[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ob[s] = *reinterpret_cast<const f16x8*>(in + xoff(rc, h, 64) + s * 512);
+        f32x16 accs[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[it][r] = bs[h * 64 + it * 16 + r];
+        gemm_h<4, 4>(&lds[kHH_AS], lane, accs, [&](int s) -> f16x8 { return ob[s]; });
+        f16x8 sb[8];
+        {
+            float r[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
+            sb[0] = to_h8<0>(r);
+            sb[1] = to_h8<8>(r);
+            sb[2] = to_h8<16>(r);
+            sb[3] = to_h8<24>(r);
+            sb[4] = to_h8<32>(r);
+            sb[5] = to_h8<40>(r);
+            sb[6] = to_h8<48>(r);
+            sb[7] = to_h8<56>(r);
+        }
+        f32x16 acc1[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[it][r] = b1[h * 64 + it * 16 + r];
+        gemm_h<8, 4>(&lds[kHH_A1], lane, acc1, [&](int s) -> f16x8 { return sb[s]; });
+        for (int q = 0; q < Q; ++q) {
+            float part = 0.f;
+            const float* w = &w2[(h * Q + q) * 64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[i], part);
+            part += __shfl_xor(part, 32);
+            part += w2[2 * Q * 64 + q];
+            if (valid && h == 0) p.out[net][(size_t)row * Q + q] = part;
+        }
+    }
+}
+
+// ---- IAF affine + causal layer with fp16 (permuted) output rows: modules.py:59, :179-180 ----------------------
+struct FrontH16Params {
+    const float* z;
+    const float* s;
+    const float* b;
+    float* x_out;
+    const float* filt[PWV_MAX_NETS];
+    _Float16* hrow[PWV_MAX_NETS];
+    int sb_stride, G, N, T, W;
+};
+
+__global__ void iaf_front_h16_kernel(const FrontH16Params p) {
+    // one thread per (block of 32 rows, net, chunk, row in block): consecutive threads write consecutive 16 B
+    const unsigned per_blk = 8u * (unsigned)p.G;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned rows = (unsigned)p.N * (unsigned)p.T;
+    const unsigned row = (idx / (32u * per_blk)) * 32u + (idx & 31u);
+    if (row >= rows) return;
+    const unsigned sub = (idx >> 5) % per_blk;
+    const unsigned t = row % (unsigned)p.T;
+    auto xval = [&](unsigned rr) -> float {
+        const float zv = p.z[rr];
+        return p.s ? fmaf(zv, p.s[(size_t)rr * p.sb_stride], p.b[(size_t)rr * p.sb_stride]) : zv;
+    };
+    if (sub == 0 && p.x_out) p.x_out[row] = xval(row);
+    const unsigned g = sub >> 3, chunk = sub & 7;          // chunk = s*2 + h
+    const int s = chunk >> 1, h = chunk & 1;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < p.W; ++k) {
+        const unsigned shift = (unsigned)(p.W - 1 - k);
+        if (shift > t) continue;
+        const float xv = xval(row - shift);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = 16 * s + 8 * (q >> 2) + 4 * h + (q & 3);
+            acc[q] = fmaf(xv, p.filt[g][k * 64 + c], acc[q]);
+        }
+    }
+    *reinterpret_cast<f16x8*>(p.hrow[g] + xoff((int)row, (int)chunk, 64)) = to_h8<0>(acc);
+}
+
+// [N,T,80] fp32 per-sample condition -> fp16 rows in the B-operand order (5 k-steps)
+__global__ void cond_to_h16_kernel(const float* __restrict__ cond, _Float16* __restrict__ out, unsigned rows) {
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // (block, chunk 0..9, row in block)
+    const unsigned row = (idx / 320u) * 32u + (idx & 31u), chunk = (idx >> 5) % 10u;
+    if (row >= rows) return;
+    const int s = chunk >> 1, h = chunk & 1;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = cond[(size_t)row * kCondC + 16 * s + 8 * (q >> 2) + 4 * h + (q & 3)];
+    *reinterpret_cast<f16x8*>(out + xoff((int)row, (int)chunk, kCondC)) = to_h8<0>(v);
+}
+
+int launch_layer_h16(const LayerParams& lp, bool cond, bool gated, int per_net, hipStream_t s) {
+    const int grid = per_net * lp.G;
+    if (cond) {
+        if (gated) hipLaunchKernelGGL((layer_h16_kernel<true, true>), dim3(grid), dim3(256), 0, s, lp);
+        else hipLaunchKernelGGL((layer_h16_kernel<true, false>), dim3(grid), dim3(256), 0, s, lp);
+    } else {
+        if (gated) hipLaunchKernelGGL((layer_h16_kernel<false, true>), dim3(grid), dim3(256), 0, s, lp);
+        else hipLaunchKernelGGL((layer_h16_kernel<false, false>), dim3(grid), dim3(256), 0, s, lp);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "fp16 layer kernel launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+int launch_head_h16(const HeadParams& hp, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(head_h16_kernel, dim3(grid), dim3(256), 0, s, hp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "fp16 head kernel launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+}  // namespace pwv
+
+using namespace pwv;
+
+extern "C" {
+
+int pwv_iaf_front_f16(const float* z, const float* s, const float* b, int sb_stride, float* x_out, int G,
+                      const float* const* filt, void* const* h16, int N, int T, int W, int R, pwv_stream_t stream) {
+    PWV_CHECK_ARG(z && filt && h16, "pwv_iaf_front_f16: NULL pointer");
+    PWV_CHECK_ARG((s == nullptr) == (b == nullptr), "pwv_iaf_front_f16: s and b must both be set or both NULL");
+    PWV_CHECK_ARG(G >= 1 && G <= PWV_MAX_NETS && R == 64, "pwv_iaf_front_f16: G in [1,2] and R == 64 required");
+    PWV_CHECK_ARG(N >= 1 && T >= 1 && W >= 1, "pwv_iaf_front_f16: bad N/T/W");
+    const long long total = ((long long)N * T + 31) / 32 * 32 * 8 * G;
+    PWV_CHECK_ARG(total < (1ll << 31), "pwv_iaf_front_f16: N*T too large");
+    FrontH16Params p{};
+    p.z = z;
+    p.s = s;
+    p.b = b;
+    p.x_out = x_out;
+    p.sb_stride = sb_stride;
+    p.G = G;
+    p.N = N;
+    p.T = T;
+    p.W = W;
+    for (int g = 0; g < G; ++g) {
+        PWV_CHECK_ARG(filt[g] && h16[g], "pwv_iaf_front_f16: NULL filter / output for net %d", g);
+        p.filt[g] = filt[g];
+        p.hrow[g] = reinterpret_cast<_Float16*>(h16[g]);
+    }
+    hipLaunchKernelGGL(iaf_front_h16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_cond_to_f16(const float* cond, void* out16, int N, int T, int C, pwv_stream_t stream) {
+    PWV_CHECK_ARG(cond && out16 && C == kCondC, "pwv_cond_to_f16: NULL pointer or C != %d", kCondC);
+    const long long total = ((long long)N * T + 31) / 32 * 32 * 10;
+    PWV_CHECK_ARG(N >= 0 && T >= 0 && total < (1ll << 31), "pwv_cond_to_f16: bad size");
+    if (total == 0) return PWV_OK;
+    hipLaunchKernelGGL(cond_to_h16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cond,
+                       reinterpret_cast<_Float16*>(out16), (unsigned)(N * T));
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+}  // extern "C"

@@ -204,7 +204,8 @@ __global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsign
 }
 
 // modules.py:59 (x = z*s + b) fused with the next flow's causal layer (modules.py:179-180):
-// h_g[row, c] = sum_k x[t-(W-1-k)] * filt_g[k,0,c].  One thread per (row, 4 channels).
+// h_g[row, c] = sum_k x[t-(W-1-k)] * filt_g[k,0,c], written in the tile32 layout (pwv_layer_common.h).
+// One thread per (block of 32 rows, net, channel quad, row in block): consecutive threads write consecutive 16 B.
 struct FrontParams {
     const float* z;
     const float* s;
@@ -219,12 +220,12 @@ __global__ void iaf_front_kernel(const FrontParams p) {
     // 32-bit index math throughout (N*T*per_row < 2^31 is checked by the launcher): a 64-bit division is
     // emulated with ~100 instructions and made this bandwidth-bound kernel ALU-bound
     const unsigned r4 = (unsigned)p.R / 4;
-    const unsigned per_row = p.G > 0 ? r4 * (unsigned)p.G : 1u;
+    const unsigned per_blk = p.G > 0 ? r4 * (unsigned)p.G : 1u;
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned rows = (unsigned)p.N * (unsigned)p.T;
-    if (idx >= rows * per_row) return;
-    const unsigned row = idx / per_row;
-    const unsigned sub = idx - row * per_row;
+    const unsigned row = (idx / (32u * per_blk)) * 32u + (idx & 31u);
+    if (row >= rows) return;
+    const unsigned sub = (idx >> 5) % per_blk;
     const unsigned t = row % (unsigned)p.T;
     auto xval = [&](unsigned rr) -> float {
         const float zv = p.z[rr];
@@ -242,7 +243,17 @@ __global__ void iaf_front_kernel(const FrontParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w[e], acc[e]);
     }
-    *reinterpret_cast<f32x4*>(p.h[g] + (size_t)row * p.R + c) = acc;
+    *reinterpret_cast<f32x4*>(p.h[g] + (size_t)(row >> 5) * (32u * p.R) + (c >> 2) * 128u + (row & 31u) * 4u) = acc;
+}
+
+// [rows, C] channels-last <-> tile32 ([block of 32 rows][C/4 quads][32 rows][4]); thread = (block, quad, row in block)
+template <bool TO_TILE>
+__global__ void tile32_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned rows, unsigned c4) {
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned row = (idx / (32u * c4)) * 32u + (idx & 31u), quad = (idx >> 5) % c4;
+    if (row >= rows) return;
+    const size_t lin = (size_t)row * c4 * 4 + quad * 4, til = (size_t)(row >> 5) * (128u * c4) + quad * 128u + (row & 31u) * 4u;
+    *reinterpret_cast<f32x4*>(out + (TO_TILE ? til : lin)) = *reinterpret_cast<const f32x4*>(in + (TO_TILE ? lin : til));
 }
 
 static inline unsigned blocks_for(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
@@ -359,11 +370,37 @@ int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_str
         p.filt[g] = filt[g];
         p.h[g] = h[g];
     }
-    const long long total = (long long)N * T * (G > 0 ? (R / 4) * G : 1);
+    const long long total = ((long long)N * T + 31) / 32 * 32 * (G > 0 ? (R / 4) * G : 1);
     PWV_CHECK_ARG(total < (1ll << 31), "pwv_iaf_front_f32: N*T*R*G/4 must stay below 2^31");
     hipLaunchKernelGGL(iaf_front_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
+}
+
+size_t pwv_tile32_floats(int64_t rows, int C) { return rows > 0 && C > 0 ? (size_t)((rows + 31) / 32) * 32 * (size_t)C : 0; }
+
+static int tile32_convert(bool to_tile, const float* in, float* out, int64_t rows, int C, pwv_stream_t stream) {
+    PWV_CHECK_ARG(in && out && in != out, "pwv tile32 conversion: NULL or aliased buffers");
+    PWV_CHECK_ARG(rows >= 0 && C >= 4 && C % 4 == 0, "pwv tile32 conversion: C must be a positive multiple of 4");
+    const long long total = (rows + 31) / 32 * 32 * (C / 4);
+    PWV_CHECK_ARG(total < (1ll << 31), "pwv tile32 conversion: rows*C/4 must stay below 2^31");
+    if (total == 0) return PWV_OK;
+    if (to_tile)
+        hipLaunchKernelGGL(tile32_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                           (unsigned)rows, (unsigned)(C / 4));
+    else
+        hipLaunchKernelGGL(tile32_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                           (unsigned)rows, (unsigned)(C / 4));
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_rows_to_tile32_f32(const float* in, float* out, int64_t rows, int C, pwv_stream_t stream) {
+    return tile32_convert(true, in, out, rows, C, stream);
+}
+
+int pwv_tile32_to_rows_f32(const float* in, float* out, int64_t rows, int C, pwv_stream_t stream) {
+    return tile32_convert(false, in, out, rows, C, stream);
 }
 
 }  // extern "C"

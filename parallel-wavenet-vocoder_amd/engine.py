@@ -4,8 +4,10 @@ This is plumbing: it owns no arithmetic.  It packs TF-layout weights once per va
 version (pwv_pack_*), allocates the ping-pong activation buffers in HBM through torch's caching
 allocator, and enqueues the per-layer launches of libpwv_hip.so on torch's current HIP stream.
 
-Data layout in HBM (all float32, channels-last):
-  residual stream   2 x [N, T, 64] per net (ping-pong; a layer reads x[t], x[t-d] and writes out[t])
+Data layout in HBM (float32):
+  residual stream   2 x (N*T rows x 64) per net in the "tile32" layout of include/pwv_hip.h (blocks of 32 rows
+                    stored [16 channel quads][32 rows][4]: every wave-level load/store is 1 KB contiguous);
+                    ping-pong: a layer reads x[t], x[t-d] and writes out[t].  fp16 blocks with precision 'f16'.
   projection P      [N*t_mel, 128*L] per net: relu(mel@dense) @ [gc_filter‖gc_gate] + biases for
                     all L layers at FRAME rate (hoisted: modules.py:216-228 are the same dot
                     products for all 80 samples of a frame), columns in the kernel's order
@@ -15,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from ctypes import c_void_p
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -27,7 +30,10 @@ from ._lib import HeadArgs, LayerArgs, StackArgs, check
 # 'f16x3': 3-term split-fp16 MFMA with fp32 accumulation (w*x ~= wh*xh + wh*xl + wl*xh, ~22-bit
 #          mantissa products): same measured accuracy vs fp64 as 'f32' (~3e-6 on the full model,
 #          bar 2e-5), 5.3x fewer matrix-pipe cycles.  Default; PWV_PRECISION overrides.
-PRECISIONS = {'f32': _lib.PREC_F32, 'f16x3': _lib.PREC_F16X3}
+# 'f16'  : BUILD EXTENSION (BASELINE.json config 5; the reference is fp32 only): fp16 residual stream in HBM,
+#          one fp16 MFMA product, fp32 accumulate.  ~1e-3 of the fp32 result -- never the default, never the
+#          headline benchmark; tolerance stated in tests/test_gpu_f16.py.
+PRECISIONS = {'f32': _lib.PREC_F32, 'f16x3': _lib.PREC_F16X3, 'f16': _lib.PREC_F16}
 DEFAULT_PRECISION = os.environ.get('PWV_PRECISION', 'f16x3')
 
 # When a list, run_nets brackets every fused-layer launch with HIP events recorded on the
@@ -196,6 +202,7 @@ class NetPlan:
 
 
 _plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
+_cond_cache = None      # (weakref(condition tensor), its version, fp16?, tile32 copy, stream it was made on)
 
 
 def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
@@ -258,8 +265,33 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
         if tuple(cond_t.shape) != (n, t, net0.condition_channels):
             raise ValueError('condition_batch %s does not match input %s / %d channels'
                              % (tuple(cond_t.shape), tuple(x.shape), net0.condition_channels))
+    half = prec == _lib.PREC_F16
+    if half and (qin != 1 or net0.use_skip_connection):
+        raise _lib.PwvError("precision 'f16' supports scalar-input nets without skip accumulation only")
     plans = [get_plan(net, mode, prec) for net in nets]
     L = plans[0].n_layers
+    rows = n * t
+
+    def tile_buf(channels, dtype=torch.float32):
+        return torch.empty((lib.pwv_tile32_floats(rows, channels),), dtype=dtype, device=dev)
+
+    if cond_t is not None:      # per-sample condition -> tile32 (fp16 blocks in 'f16' mode)
+        # every flow of a forward pass is handed the same tensor: convert it once (the entry is valid while that
+        # very tensor object is alive and has not been written to)
+        global _cond_cache
+        hit = _cond_cache
+        if (hit is not None and hit[0]() is cond_t and hit[1] == cond_t._version and hit[2] == half
+                and hit[4] == torch.cuda.current_stream()):
+            cond_t = hit[3]
+        else:
+            cc = cond_t.shape[2]
+            ct = tile_buf(cc, torch.float16 if half else torch.float32)
+            if half:
+                check(lib.pwv_cond_to_f16(_ptr(cond_t), _ptr(ct), n, t, cc, s), 'pwv_cond_to_f16')
+            else:
+                check(lib.pwv_rows_to_tile32_f32(_ptr(cond_t), _ptr(ct), rows, cc, s), 'pwv_rows_to_tile32_f32')
+            _cond_cache = (weakref.ref(cond_t), cond_t._version, half, ct, torch.cuda.current_stream())
+            cond_t = ct
 
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
     main = torch.cuda.current_stream()
@@ -283,20 +315,22 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
 
     # ---- causal layer (modules.py:174-183) ----------------------------------------------------
     R = net0.residual_channels
-    bufs = [[torch.empty((n, t, R), dtype=torch.float32, device=dev) for _ in range(2)] for _ in nets]
+    bufs = [[tile_buf(R, torch.float16 if half else torch.float32) for _ in range(2)] for _ in nets]
     if qin == 1:
         filt = (c_void_p * G)(*[p.causal_filter.data_ptr() for p in plans])
         hout = (c_void_p * G)(*[b[0].data_ptr() for b in bufs])
-        check(lib.pwv_iaf_front_f32(_ptr(x), None, None, 1, None, G, filt, hout, n, t, net0.filter_width, R, s),
-              'pwv_iaf_front_f32')
+        front = lib.pwv_iaf_front_f16 if half else lib.pwv_iaf_front_f32
+        check(front(_ptr(x), None, None, 1, None, G, filt, hout, n, t, net0.filter_width, R, s), 'pwv_iaf_front')
     else:
-        for g, p in enumerate(plans):
-            check(lib.pwv_causal_conv_f32(_ptr(x), _ptr(p.causal_filter), _ptr(bufs[g][0]), n, t, qin, R,
+        for g, p in enumerate(plans):      # multi-channel input: generic causal conv, then into tile32
+            hrows = torch.empty((n, t, R), dtype=torch.float32, device=dev)
+            check(lib.pwv_causal_conv_f32(_ptr(x), _ptr(p.causal_filter), _ptr(hrows), n, t, qin, R,
                                           net0.filter_width, 1, s), 'pwv_causal_conv_f32')
+            check(lib.pwv_rows_to_tile32_f32(_ptr(hrows), _ptr(bufs[g][0]), rows, R, s), 'pwv_rows_to_tile32_f32')
 
 
     use_skip = bool(net0.use_skip_connection)
-    skips = [torch.empty((n, t, net0.skip_channels), dtype=torch.float32, device=dev) for _ in nets] if use_skip else None
+    skips = [tile_buf(net0.skip_channels) for _ in nets] if use_skip else None
     Q = net0.out_channels
     outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
 

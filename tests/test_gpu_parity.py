@@ -249,3 +249,46 @@ def test_misuse_raises(gpu):
     with pytest.raises(AssertionError):
         IAFVocoder(1, 80, store=store)(None, torch.zeros(1, 3, 80, device=gpu), False)
     set_hparams(cfg)
+
+
+@pytest.mark.parametrize('rows,C', [(1, 4), (31, 64), (32, 64), (33, 80), (1000, 128)])
+def test_tile32_round_trip(gpu, rows, C):
+    """include/pwv_hip.h: float index of (row, c) = (row/32)*32*C + (c/4)*128 + (row%32)*4 + c%4."""
+    import ctypes
+    import torch
+    from pwv_amd import _lib
+    lib = _lib.lib()
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(rows, C, device=gpu)
+    nf = lib.pwv_tile32_floats(rows, C)
+    blocks = (rows + 31) // 32
+    assert nf == blocks * 32 * C
+    tiled = torch.full((nf,), -7.0, device=gpu)
+    _lib.check(lib.pwv_rows_to_tile32_f32(x.data_ptr(), tiled.data_ptr(), rows, C, s))
+    pad = torch.full((blocks * 32, C), -7.0, device=gpu)
+    pad[:rows] = x
+    want = pad.reshape(blocks, 32, C // 4, 4).permute(0, 2, 1, 3).reshape(-1)
+    assert torch.equal(tiled, want)
+    back = torch.empty_like(x)
+    _lib.check(lib.pwv_tile32_to_rows_f32(tiled.data_ptr(), back.data_ptr(), rows, C, s))
+    assert torch.equal(back, x)
+
+
+def test_sample_condition_cache_sees_in_place_updates(gpu):
+    """The tile32 copy of a per-sample condition is reused across the flows of a forward pass; writing to the
+    tensor in place (or passing a different one) must not be served from that copy."""
+    import torch
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    store = VariableStore(device=gpu)
+    net = WaveNet(batch_size=2, dilations=[1, 2, 4], filter_width=2, residual_channels=64, dilation_channels=64,
+                  skip_channels=128, quantization_channels=1, input_channels=1, use_biases=True, condition_channels=80,
+                  use_skip_connection=False, name='scalar', store=store)
+    x = torch.randn(2, 100, 1, device=gpu)
+    cond = torch.randn(2, 100, 80, device=gpu)
+    y0 = net(x, cond)
+    assert torch.equal(net(x, cond), y0)
+    cond.mul_(0.5)
+    y1 = net(x, cond)
+    assert not torch.equal(y1, y0)
+    assert torch.equal(net(x, cond.clone()), y1)

@@ -54,3 +54,28 @@ def small_cfg(**kw):
     base = dict(dilations=[[1, 2, 4], [1, 2, 4, 8]], n_iaf=2)
     base.update(kw)
     return O.ModelConfig(**base)
+
+
+def f16_storage_model(weights, cfg):
+    """What the PWV_PREC_F16 build extension computes, restated for the fp64 oracle: the weights as its kernels
+    hold them (fp16 after the exp2 scale folding of csrc/pwv_layer_common.h; dense / skip / postprocess1 plain
+    fp16; everything at frame rate, biases and postprocess2 stay fp32) and the hook that rounds every activation
+    the mode stores as fp16 (oracle.wavenet_forward(act_round=...)).  Returns (weights, act_round)."""
+    k_f, k_g = np.float32(-2.8853900817779268), np.float32(-1.4426950408889634)
+
+    def r16(a):
+        return np.asarray(a).astype(np.float16).astype(np.float64)
+
+    per_sample_cond = cfg.cond_upsample_method == 'transposed_conv'
+    out = {}
+    for name, v in weights.items():
+        leaf = name.rsplit('/', 1)[1]
+        in_stack = '/dilated_stack/' in name
+        if in_stack and (leaf in ('filter', 'gate') or (per_sample_cond and leaf in ('gc_filter', 'gc_gate'))):
+            k = k_f if leaf in ('filter', 'gc_filter') else k_g
+            out[name] = r16(k * v.astype(np.float32)) / np.float64(k)
+        elif (in_stack and leaf in ('dense', 'skip')) or leaf == 'postprocess1':
+            out[name] = r16(v)
+        else:
+            out[name] = v
+    return out, r16

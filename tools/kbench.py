@@ -21,7 +21,7 @@ def main():
     ap.add_argument('--dilation', type=int, default=64)
     ap.add_argument('--G', type=int, default=2)
     ap.add_argument('--zero', action='store_true', help='all-zero activations and weights (power / DVFS probe)')
-    ap.add_argument('--precision', type=int, default=0, help='0 = f32, 1 = f16x3')
+    ap.add_argument('--precision', type=int, default=0, help='0 = f32, 1 = f16x3, 2 = f16')
     args = ap.parse_args()
     _lib.build_library()
     lib = _lib.lib()
@@ -31,6 +31,8 @@ def main():
     nf = lib.pwv_layer_packed_floats(0, 0)
     scale = 0.0 if args.zero else 1.0
     xs = [[torch.randn(rows, 64, device=dev) * scale for _ in range(2)] for _ in range(G)]
+    if args.precision == 2:      # fp16 rows
+        xs = [[x.half() for x in pair] for pair in xs]
     packed = [torch.randn(nf, device=dev) * 0.05 * scale for _ in range(G)]
     proj = [torch.randn(128, device=dev) * 0.1 * scale for _ in range(G)]
     a = LayerArgs()
