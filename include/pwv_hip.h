@@ -110,7 +110,7 @@ int pwv_tile32_to_rows_f32(const float* in, float* out, int64_t rows, int C, pwv
  *   h_g[n,t,:] = sum_k x[n, t-(W-1-k), 0] * filt_g[k,0,:]  modules.py:179-180 (no bias)
  * z [N*T]; s, b strided views of the previous flow's net outputs; x_out [N*T] (may be NULL
  * when s == NULL); for g < G: filt[g] is [W,1,R], h[g] is a tile32 buffer of N*T rows x R channels
- * (see below).  G may be 0 (affine only).
+ * (see below).  G may be 0 (affine only).  W <= 8 and W*R <= 2048 (the filter is staged in LDS).
  * ------------------------------------------------------------------------------------- */
 int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_stride,
                       float* x_out, int G, const float* const* filt, float* const* h,

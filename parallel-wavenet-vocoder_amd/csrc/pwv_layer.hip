@@ -669,9 +669,10 @@ int pwv_wavenet_head_f32(const pwv_head_args* a, pwv_stream_t stream) {
     const int cus = device_cus();
     if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
     const long long rows = (long long)a->N * a->T;
-    const int ntiles = (int)((rows + 127) / 128);
+    int ntiles = (int)((rows + 127) / 128);
     int per_net = (a->max_workgroups > 0 ? a->max_workgroups : cus) / a->G;
     if (per_net < 1) per_net = 1;
+    if (a->precision == PWV_PREC_F16X3) ntiles = (int)((rows + 255) / 256);   // 8-wave workgroups: >= 1 unit per wave
     if (a->precision == PWV_PREC_F16) {
         PWV_CHECK_ARG(a->in_mode == PWV_HEAD_IN_GATED, "pwv_wavenet_head_f32: PWV_PREC_F16 needs in_mode PWV_HEAD_IN_GATED");
         per_net *= 3;

@@ -362,12 +362,14 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 }
 
 // --------------------------------------------------------------------------------------
-// head, split-fp16 arithmetic (4 waves, static tiles; post2 stays an fp32 VALU dot)
+// head, split-fp16 arithmetic (8 waves = 2 per SIMD, dynamic 32-row units out of a contiguous per-workgroup
+// range like the layer kernel; post2 stays an fp32 VALU dot)
 // --------------------------------------------------------------------------------------
 template <bool FROM_GATED>
-__global__ __launch_bounds__(256) void head_f16x3_kernel(const HeadParams p) {
+__global__ __launch_bounds__(512) void head_f16x3_kernel(const HeadParams p) {
+    constexpr int WAVES = 8;
     constexpr int kLds = head_floats(kMaxQ);
-    __shared__ __attribute__((aligned(16))) float lds[kLds];
+    __shared__ __attribute__((aligned(16))) float lds[kLds + 4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,15 +378,26 @@ __global__ __launch_bounds__(256) void head_f16x3_kernel(const HeadParams p) {
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
     const int Q = p.Q;
-    fill_lds<head_floats(kMaxQ) / 4, 256>(lds, p.packed[net], tid);   // buffers are sized for kMaxQ
+    int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
+    if (tid == 0) *unit_counter = WAVES;
+    fill_lds<head_floats(kMaxQ) / 4, 64 * WAVES>(lds, p.packed[net], tid);   // buffers are sized for kMaxQ
     __syncthreads();
     const f16x8* HAS = reinterpret_cast<const f16x8*>(&lds[kHAS]);
     const f16x8* HA1 = reinterpret_cast<const f16x8*>(&lds[kHA1]);
     auto no_extra = [](int) {};
     const int rows = p.N * p.T;
-    const int ntiles = (rows + 127) / 128;
-    for (int tile = wg; tile < ntiles; tile += nwg) {
-        const int row = tile * 128 + wave * 32 + (lane & 31);
+    const int units = (rows + 31) / 32;
+    const int per_wg = (units + nwg - 1) / nwg;
+    const int u_begin = wg * per_wg;
+    const int u_end = (u_begin + per_wg < units) ? u_begin + per_wg : units;
+    auto grab = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(unit_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return u_begin + __builtin_amdgcn_readfirstlane(v);
+    };
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    for (int unit = u_begin + wave; unit < u_end; unit = grab()) {
+        const int row = unit * 32 + (lane & 31);
         const bool valid = row < rows;
         const int rc = valid ? row : rows - 1;
         f32x16 accs[4];
@@ -645,9 +658,9 @@ int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, 
 
 int launch_head_f16x3(const HeadParams& hp, bool from_gated, int grid, hipStream_t s) {
     if (from_gated)
-        hipLaunchKernelGGL((head_f16x3_kernel<true>), dim3(grid), dim3(256), 0, s, hp);
+        hipLaunchKernelGGL((head_f16x3_kernel<true>), dim3(grid), dim3(512), 0, s, hp);
     else
-        hipLaunchKernelGGL((head_f16x3_kernel<false>), dim3(grid), dim3(256), 0, s, hp);
+        hipLaunchKernelGGL((head_f16x3_kernel<false>), dim3(grid), dim3(512), 0, s, hp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 head kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;

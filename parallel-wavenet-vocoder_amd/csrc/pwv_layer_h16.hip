@@ -289,34 +289,49 @@ struct FrontH16Params {
     int sb_stride, G, N, T, W;
 };
 
-__global__ void iaf_front_h16_kernel(const FrontH16Params p) {
-    // one thread per (block of 32 rows, net, chunk, row in block): consecutive threads write consecutive 16 B
-    const unsigned per_blk = 8u * (unsigned)p.G;
-    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kFrontH16MaxTaps = 8;
+
+// one thread per row (blockIdx.y = net), filter [W][64] in LDS (broadcast reads), 8 chunk stores of 16 bytes
+__global__ __launch_bounds__(256) void iaf_front_h16_kernel(const FrontH16Params p) {
+    __shared__ __attribute__((aligned(16))) float fl[kFrontH16MaxTaps * 64];
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < p.W * 64; i += 256) fl[i] = p.filt[g][i];
+    __syncthreads();
     const unsigned rows = (unsigned)p.N * (unsigned)p.T;
-    const unsigned row = (idx / (32u * per_blk)) * 32u + (idx & 31u);
+    const unsigned row = blockIdx.x * 256u + threadIdx.x;
     if (row >= rows) return;
-    const unsigned sub = (idx >> 5) % per_blk;
     const unsigned t = row % (unsigned)p.T;
     auto xval = [&](unsigned rr) -> float {
         const float zv = p.z[rr];
         return p.s ? fmaf(zv, p.s[(size_t)rr * p.sb_stride], p.b[(size_t)rr * p.sb_stride]) : zv;
     };
-    if (sub == 0 && p.x_out) p.x_out[row] = xval(row);
-    const unsigned g = sub >> 3, chunk = sub & 7;          // chunk = s*2 + h
-    const int s = chunk >> 1, h = chunk & 1;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < p.W; ++k) {
-        const unsigned shift = (unsigned)(p.W - 1 - k);
-        if (shift > t) continue;
-        const float xv = xval(row - shift);
+    const float xcur = xval(row);
+    float xv[kFrontH16MaxTaps];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = 16 * s + 8 * (q >> 2) + 4 * h + (q & 3);
-            acc[q] = fmaf(xv, p.filt[g][k * 64 + c], acc[q]);
-        }
+    for (int k = 0; k < kFrontH16MaxTaps; ++k) {
+        const unsigned shift = (unsigned)(p.W - 1 - k);
+        xv[k] = k + 1 == p.W ? xcur : ((k < p.W && shift <= t) ? xval(row - shift) : 0.f);
     }
-    *reinterpret_cast<f16x8*>(p.hrow[g] + xoff((int)row, (int)chunk, 64)) = to_h8<0>(acc);
+    if (g == 0 && p.x_out) p.x_out[row] = xcur;
+    _Float16* out = p.hrow[g] + xoff((int)row, 0, 64);
+#pragma unroll
+    for (int chunk = 0; chunk < 8; ++chunk) {
+        const int s = chunk >> 1, h = chunk & 1;      // halves q <-> channels 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3}
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < kFrontH16MaxTaps; ++k) {
+            if (k < p.W) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&fl[k * 64 + 16 * s + 4 * h]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&fl[k * 64 + 16 * s + 8 + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = fmaf(xv[k], w0[e], acc[e]);
+                    acc[4 + e] = fmaf(xv[k], w1[e], acc[4 + e]);
+                }
+            }
+        }
+        *reinterpret_cast<f16x8*>(out + chunk * 256) = to_h8<0>(acc);
+    }
 }
 
 // [N,T,80] fp32 per-sample condition -> fp16 rows in the B-operand order (5 k-steps)
@@ -364,8 +379,8 @@ int pwv_iaf_front_f16(const float* z, const float* s, const float* b, int sb_str
     PWV_CHECK_ARG((s == nullptr) == (b == nullptr), "pwv_iaf_front_f16: s and b must both be set or both NULL");
     PWV_CHECK_ARG(G >= 1 && G <= PWV_MAX_NETS && R == 64, "pwv_iaf_front_f16: G in [1,2] and R == 64 required");
     PWV_CHECK_ARG(N >= 1 && T >= 1 && W >= 1, "pwv_iaf_front_f16: bad N/T/W");
-    const long long total = ((long long)N * T + 31) / 32 * 32 * 8 * G;
-    PWV_CHECK_ARG(total < (1ll << 31), "pwv_iaf_front_f16: N*T too large");
+    PWV_CHECK_ARG((long long)N * T < (1ll << 31) - 256, "pwv_iaf_front_f16: N*T too large");
+    PWV_CHECK_ARG(W <= kFrontH16MaxTaps, "pwv_iaf_front_f16: W must be <= %d", kFrontH16MaxTaps);
     FrontH16Params p{};
     p.z = z;
     p.s = s;
@@ -381,7 +396,7 @@ int pwv_iaf_front_f16(const float* z, const float* s, const float* b, int sb_str
         p.filt[g] = filt[g];
         p.hrow[g] = reinterpret_cast<_Float16*>(h16[g]);
     }
-    hipLaunchKernelGGL(iaf_front_h16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(iaf_front_h16_kernel, dim3((unsigned)(((long long)N * T + 255) / 256), G), dim3(256), 0, (hipStream_t)stream, p);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

@@ -216,34 +216,50 @@ struct FrontParams {
     int sb_stride, G, N, T, W, R;
 };
 
-__global__ void iaf_front_kernel(const FrontParams p) {
-    // 32-bit index math throughout (N*T*per_row < 2^31 is checked by the launcher): a 64-bit division is
-    // emulated with ~100 instructions and made this bandwidth-bound kernel ALU-bound
-    const unsigned r4 = (unsigned)p.R / 4;
-    const unsigned per_blk = p.G > 0 ? r4 * (unsigned)p.G : 1u;
-    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kFrontMaxTaps = 8;         // filter widths the fused front end supports
+constexpr int kFrontMaxFilt = 2048;      // W * R floats staged per workgroup
+
+// One thread per row (blockIdx.y = net): x[t-(W-1)..t] once, then R/4 channel quads, each a 16-byte store that is
+// contiguous across the 32 lanes of a tile32 block.  The filter (W*R floats) sits in LDS: every lane reads the same
+// words (broadcast).  The previous thread-per-quad version spent its time in three 32-bit divisions per 16 bytes.
+__global__ __launch_bounds__(256) void iaf_front_kernel(const FrontParams p) {
+    __shared__ __attribute__((aligned(16))) float fl[kFrontMaxFilt];
+    const int g = blockIdx.y;
+    if (p.G > 0) {
+        for (int i = threadIdx.x; i < p.W * p.R; i += 256) fl[i] = p.filt[g][i];
+        __syncthreads();
+    }
     const unsigned rows = (unsigned)p.N * (unsigned)p.T;
-    const unsigned row = (idx / (32u * per_blk)) * 32u + (idx & 31u);
+    const unsigned row = blockIdx.x * 256u + threadIdx.x;
     if (row >= rows) return;
-    const unsigned sub = (idx >> 5) % per_blk;
     const unsigned t = row % (unsigned)p.T;
     auto xval = [&](unsigned rr) -> float {
         const float zv = p.z[rr];
         return p.s ? fmaf(zv, p.s[(size_t)rr * p.sb_stride], p.b[(size_t)rr * p.sb_stride]) : zv;
     };
-    if (sub == 0 && p.x_out) p.x_out[row] = xval(row);
-    if (p.G == 0) return;
-    const unsigned g = sub / r4, c = (sub - g * r4) * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.W; ++k) {
-        const unsigned shift = (unsigned)(p.W - 1 - k);
-        if (shift > t) continue;
-        const float xv = xval(row - shift);
-        const f32x4 w = *reinterpret_cast<const f32x4*>(p.filt[g] + (size_t)k * p.R + c);
+    const float xcur = xval(row);
+    float xv[kFrontMaxTaps];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w[e], acc[e]);
+    for (int k = 0; k < kFrontMaxTaps; ++k) {
+        const unsigned shift = (unsigned)(p.W - 1 - k);      // tap k multiplies x[t - (W-1-k)], zero left of the utterance start
+        xv[k] = k + 1 == p.W ? xcur : ((k < p.W && shift <= t) ? xval(row - shift) : 0.f);
     }
-    *reinterpret_cast<f32x4*>(p.h[g] + (size_t)(row >> 5) * (32u * p.R) + (c >> 2) * 128u + (row & 31u) * 4u) = acc;
+    if (g == 0 && p.x_out) p.x_out[row] = xcur;
+    if (p.G == 0) return;
+    float* out = p.h[g] + (size_t)(row >> 5) * (32u * p.R) + (row & 31u) * 4u;
+    const int r4 = p.R / 4;
+    for (int q = 0; q < r4; ++q) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kFrontMaxTaps; ++k) {
+            if (k < p.W) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&fl[k * p.R + 4 * q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[k], w[e], acc[e]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + q * 128) = acc;
+    }
 }
 
 // [rows, C] channels-last <-> tile32 ([block of 32 rows][C/4 quads][32 rows][4]); thread = (block, quad, row in block)
@@ -370,9 +386,11 @@ int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_str
         p.filt[g] = filt[g];
         p.h[g] = h[g];
     }
-    const long long total = ((long long)N * T + 31) / 32 * 32 * (G > 0 ? (R / 4) * G : 1);
-    PWV_CHECK_ARG(total < (1ll << 31), "pwv_iaf_front_f32: N*T*R*G/4 must stay below 2^31");
-    hipLaunchKernelGGL(iaf_front_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    PWV_CHECK_ARG((long long)N * T < (1ll << 31) - 256, "pwv_iaf_front_f32: N*T must stay below 2^31");
+    PWV_CHECK_ARG(G == 0 || (W <= kFrontMaxTaps && W * R <= kFrontMaxFilt),
+                  "pwv_iaf_front_f32: filter width %d / %d channels not supported (W <= %d, W*R <= %d)", W, R, kFrontMaxTaps, kFrontMaxFilt);
+    PWV_CHECK_ARG(W <= kFrontMaxTaps, "pwv_iaf_front_f32: W must be <= %d", kFrontMaxTaps);
+    hipLaunchKernelGGL(iaf_front_kernel, dim3(blocks_for((long long)N * T, 256), G > 0 ? G : 1), dim3(256), 0, (hipStream_t)stream, p);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--dilation', type=int, default=64)
     ap.add_argument('--G', type=int, default=2)
     ap.add_argument('--zero', action='store_true', help='all-zero activations and weights (power / DVFS probe)')
+    ap.add_argument('--cold-weights', type=int, default=1, help='rotate through this many distinct packed weight buffers')
     ap.add_argument('--precision', type=int, default=0, help='0 = f32, 1 = f16x3, 2 = f16')
     args = ap.parse_args()
     _lib.build_library()
@@ -34,6 +35,7 @@ def main():
     if args.precision == 2:      # fp16 rows
         xs = [[x.half() for x in pair] for pair in xs]
     packed = [torch.randn(nf, device=dev) * 0.05 * scale for _ in range(G)]
+    rot = [[torch.randn(nf, device=dev) * 0.05 * scale for _ in range(G)] for _ in range(args.cold_weights)]
     proj = [torch.randn(128, device=dev) * 0.1 * scale for _ in range(G)]
     a = LayerArgs()
     a.G = G
@@ -54,7 +56,10 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(args.iters):
+        for it in range(args.iters):
+            if args.cold_weights > 1:
+                for g in range(G):
+                    a.packed[g] = rot[it % args.cold_weights][g].data_ptr()
             check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), s))
         e1.record()
         torch.cuda.synchronize()
