@@ -107,7 +107,10 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     const int nwg = gridDim.x / p.G;
     int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
 #ifdef PWV_TRACE
-    if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    if (p.trace && tid == 0) {
+        p.trace[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        p.trace[4096 + 1024 + blockIdx.x * 2 + 0] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
+    }
 #endif
     // the first WAVES units are handed out statically (wave w takes unit w) so their rows can be
     // requested before the weights are staged; the counter then starts at WAVES
@@ -357,6 +360,8 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_max(&p.trace[4096 + blockIdx.x * 4 + 2], (long long)__builtin_amdgcn_s_memtime(), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&p.trace[4096 + 1024 + blockIdx.x * 2 + 1], (long long)__builtin_amdgcn_s_memrealtime(),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
 }

@@ -46,7 +46,12 @@ for _ in range(3):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
 full = trace.cpu().numpy()
-wgt = full[4096:].reshape(-1, 4)
+rt = full[4096 + 1024:4096 + 1024 + 512].reshape(-1, 2)
+rt = rt[rt[:, 0] > 0]
+print('chip-wide clock (100 MHz): first WG start -> last WG end %.2f us; WG starts spread over %.2f us, ends over %.2f us; '
+      'mean WG lifetime %.2f us' % ((rt[:, 1].max() - rt[:, 0].min()) / 100.0, (rt[:, 0].max() - rt[:, 0].min()) / 100.0,
+                                     (rt[:, 1].max() - rt[:, 1].min()) / 100.0, (rt[:, 1] - rt[:, 0]).mean() / 100.0))
+wgt = full[4096:4096 + 1024].reshape(-1, 4)
 wgt = wgt[wgt[:, 0] > 0]
 dur = wgt[:, 2] - wgt[:, 0]          # per-WG: entry -> last wave done (s_memtime is per-XCD: only differences within a WG mean anything)
 fill = wgt[:, 1] - wgt[:, 0]
