@@ -71,6 +71,11 @@ int pwv_causal_conv_f32(const float* x, const float* filt, float* y,
 int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y,
                    int M, int K, int Nout, int relu, pwv_stream_t stream);
 
+/* same contract in split-fp16 arithmetic (3 fp16 MFMA products per term, fp32 accumulate, ~2^-22
+ * relative per product: the arithmetic of PWV_PREC_F16X3); 5x fewer matrix-pipe cycles */
+int pwv_linear_split_f32(const float* x, const float* w, const float* bias, float* y,
+                         int M, int K, int Nout, int relu, pwv_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * IAFVocoder._upsample_cond, 'repeat' branch: tile + reshape + crop   models.py:131-133
  *   out[n, t, :] = frames[n, (t + offset) / hop, :],  t in [0, T)

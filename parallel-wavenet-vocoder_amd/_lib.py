@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
+    'pwv_linear_split_f32',
 )
 
 
@@ -124,6 +125,7 @@ def _declare(lib):
     lib.pwv_device_cus.restype = c_int
     lib.pwv_causal_conv_f32.argtypes = [f32p, f32p, f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.pwv_linear_f32.argtypes = [f32p, f32p, f32p, f32p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.pwv_linear_split_f32.argtypes = lib.pwv_linear_f32.argtypes
     lib.pwv_upsample_repeat_f32.argtypes = [f32p, f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.pwv_crop_time_f32.argtypes = [f32p, f32p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.pwv_logistic_noise_f32.argtypes = [f32p, c_int64, c_uint64, c_uint64, c_void_p]

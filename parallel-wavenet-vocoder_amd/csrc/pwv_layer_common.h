@@ -151,6 +151,23 @@ __host__ __device__ inline size_t tile32_floats(long long rows, int C) { return 
 __device__ __forceinline__ size_t tile_off(int row, int quad, int C) {
     return (size_t)(row >> 5) * (32 * C) + quad * 128 + (row & 31) * 4;
 }
+// The same copy by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write pass): wave w moves the 1 KB chunks
+// w, w + WAVES, ...; chunk c lands at lds + 256 c floats + 16 bytes x lane (the destination of an LDS-DMA is
+// wave-uniform base + lane x size, so packed order == LDS order is exactly what it needs).  The transfers count on
+// vmcnt; the __syncthreads() that follows waits for them and orders them for every reader.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int N4, int WAVES>
+__device__ __forceinline__ void fill_lds_dma(float* lds, const float* __restrict__ packed, int wave, int lane) {
+    constexpr int CH = (N4 + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < (CH + WAVES - 1) / WAVES; ++i) {
+        const int c = wave + i * WAVES;
+        if (c < CH && c * 64 + lane < N4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(packed + (size_t)(c * 64 + lane) * 4), (lptr_t)(lds + c * 256), 16, 0, 0);
+    }
+}
+
 // lane (t,h) loads channel quads 2g + h, g < NCH, of row `row` (always a valid row: callers clamp);
 // `keep == false` zeroes the result with v_cndmask instead of branching around the loads.
 template <int NCH, int C>

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     int unit = u_begin + wave;
     float rxb[32], rxc[32];      // raw rows of the current unit (prefetched during the previous unit's GEMM2)
     load_x(unit, rxb, rxc);      // in flight while the weights are staged
-    fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
+    fill_lds_dma<kLds / 4, WAVES>(lds, p.packed[net], wave, lane);
     __syncthreads();
 #ifdef PWV_TRACE
     if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();

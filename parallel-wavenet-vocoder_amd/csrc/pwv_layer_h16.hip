@@ -35,23 +35,7 @@ __device__ __forceinline__ f16x8 to_h8(const float (&x)[N]) {
     return r;
 }
 
-// only the `hi` component of a split-fp16 section is staged: NIT*NS*64 16-byte units starting at the section base
-template <int UNITS, int THREADS>
-__device__ __forceinline__ void fill_hi(f16x8* dst, const float* __restrict__ packed_section, int tid) {
-    constexpr int ITERS = (UNITS + THREADS - 1) / THREADS;
-    const f16x8* src = reinterpret_cast<const f16x8*>(packed_section);
-    f16x8 v[ITERS];
-#pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-        const int idx = tid + i * THREADS;
-        v[i] = src[idx < UNITS ? idx : UNITS - 1];
-    }
-#pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-        const int idx = tid + i * THREADS;
-        if (idx < UNITS) dst[idx] = v[i];
-    }
-}
+// only the `hi` component of each split-fp16 section is staged (fill_lds_dma on the first half of the section)
 
 // GEMM over NS k-steps with NIT row tiles, fragments prefetched one k-step ahead
 template <int NS, int NIT, int NACC, typename BF>
@@ -104,9 +88,9 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
     const int nwg = gridDim.x / p.G;
     const float* packed = p.packed[net];
     // the split-fp16 packed layout keeps [hi | lo] per section; only the hi halves are staged
-    fill_hi<4 * 8 * 64, 256>(&lds[kH_A1], packed + kA1, tid);
-    fill_hi<2 * 4 * 64, 256>(&lds[kH_A2], packed + kA2, tid);
-    if constexpr (COND) fill_hi<4 * 5 * 64, 256>(&lds[kH_AC], packed + kLayerBase, tid);
+    fill_lds_dma<4 * 8 * 64, WAVES>(reinterpret_cast<float*>(&lds[kH_A1]), packed + kA1, wave, lane);
+    fill_lds_dma<2 * 4 * 64, WAVES>(reinterpret_cast<float*>(&lds[kH_A2]), packed + kA2, wave, lane);
+    if constexpr (COND) fill_lds_dma<4 * 5 * 64, WAVES>(reinterpret_cast<float*>(&lds[kH_AC]), packed + kLayerBase, wave, lane);
     if (tid < 64) bd_lds[tid] = packed[kBD + tid];
     if (tid == 0) *unit_counter = WAVES;
     __syncthreads();
@@ -222,8 +206,8 @@ __global__ __launch_bounds__(256) void head_h16_kernel(const HeadParams p) {
     const int nwg = gridDim.x / p.G;
     const int Q = p.Q;
     const float* packed = p.packed[net];
-    fill_hi<4 * 4 * 64, 256>(&lds[kHH_AS], packed + kHAS, tid);
-    fill_hi<4 * 8 * 64, 256>(&lds[kHH_A1], packed + kHA1, tid);
+    fill_lds_dma<4 * 4 * 64, 4>(reinterpret_cast<float*>(&lds[kHH_AS]), packed + kHAS, wave, lane);
+    fill_lds_dma<4 * 8 * 64, 4>(reinterpret_cast<float*>(&lds[kHH_A1]), packed + kHA1, wave, lane);
     if (tid < 128) {
         bs[tid] = packed[kHBS + tid];
         b1[tid] = packed[kHB1 + tid];

@@ -160,6 +160,118 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
+// --------------------------------------------------------------------------------------
+// The same GEMM in split-fp16 arithmetic (w*x ~= wh*xh + wh*xl + wl*xh on v_mfma_f32_32x32x16_f16, fp32
+// accumulate: the arithmetic of the default fused layer kernels, see pwv_layer_f16.hip) -- 5.3x fewer
+// matrix-pipe cycles than the fp32 MFMA version for the same ~2^-22 products.  Used for the frame-rate
+// projection P and the conditioning GEMMs when the net runs in 'f16x3' / 'f16' precision.
+// A workgroup owns a 128-wide column block: w[:, n0:n0+128] is split and staged once into LDS as A fragments
+// ([hi|lo][4 column tiles][NS k-steps][64 lanes] x 8 halfs: k = 16 s + 8 h + q), its 4 waves walk 32-row tiles;
+// lane (m, h) loads the 8 contiguous floats x[m, 16 s + 8 h ..] of every k-step and splits them in registers.
+// --------------------------------------------------------------------------------------
+typedef float f32x2m __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8m(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const f32x2m v = {x[q], x[q + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f32x2m r = v - __builtin_convertvector(h, f32x2m);
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[q] = h[0];
+        hi[q + 1] = h[1];
+        lo[q] = l[0];
+        lo[q + 1] = l[1];
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                           int K, int Nout, int relu) {
+    __shared__ __attribute__((aligned(16))) f16x8 lds[2 * 4 * NS * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int n0 = blockIdx.y * 128;
+    // stage: one item = (column c, k-step s, half h): 8 k values -> one hi and one lo fragment unit.
+    // consecutive threads take consecutive columns (coalesced dword loads along n for each k)
+    for (int item = tid; item < 128 * NS * 2; item += 256) {
+        const int c = item & 127, sh = item >> 7, ss = sh >> 1, hh = sh & 1;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * ss + 8 * hh + q;
+            v[q] = (k < K && n0 + c < Nout) ? w[(size_t)k * Nout + n0 + c] : 0.f;
+        }
+        f16x8 hi, lo;
+        split8m(v, hi, lo);
+        const int unit = ((c >> 5) * NS + ss) * 64 + hh * 32 + (c & 31);
+        lds[unit] = hi;
+        lds[4 * NS * 64 + unit] = lo;
+    }
+    __syncthreads();
+    const f16x8* AH = lds;
+    const f16x8* AL = lds + 4 * NS * 64;
+    const int row_tiles = (M + 31) / 32;
+    for (int rt = blockIdx.x * 4 + wave; rt < row_tiles; rt += gridDim.x * 4) {
+        const int m = rt * 32 + j;
+        const bool mvalid = m < M;
+        const int mc = mvalid ? m : M - 1;
+        f16x8 bh[NS], bl[NS];
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int k = 16 * ss + 8 * h + 4 * g;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (k < K) t = *reinterpret_cast<const f32x4*>(x + (size_t)mc * K + k);   // K % 8 == 0: whole float4s
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = t[e];
+            }
+            split8m(v, bh[ss], bl[ss]);
+        }
+        // MFMA rows = rows m (A = x fragments from registers), MFMA columns = output columns n (B = w fragments
+        // from LDS): lane (j, h) then holds column n0 + 32 it + j of 16 rows, and every store instruction writes two
+        // full 128-byte lines
+        f32x16 acc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = n0 + 32 * it + j;
+            const float bv = (bias && n < Nout) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][r] = bv;
+        }
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                ah[it] = AH[(it * NS + ss) * 64 + lane];
+                al[it] = AL[(it * NS + ss) * 64 + lane];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ss], ah[it], acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ss], ah[it], acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ss], al[it], acc[it], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = n0 + 32 * it + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = rt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                float v = acc[it][r];
+                if (relu) v = fmaxf(v, 0.f);
+                if (mr < M && n < Nout) y[(size_t)mr * Nout + n] = v;
+            }
+        }
+    }
+}
+
 // models.py:131-133: out[n,t,:] = frames[n,(t+offset)/hop,:]
 __global__ void upsample_repeat_kernel(const float* __restrict__ frames, float* __restrict__ out, int N, int t_mel,
                                        int C4, int T, int hop, int offset) {
@@ -322,6 +434,29 @@ int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y, 
         hipLaunchKernelGGL((linear_kernel<10>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
     else
         hipLaunchKernelGGL((linear_kernel<16>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_linear_split_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int Nout, int relu,
+                         pwv_stream_t stream) {
+    PWV_CHECK_ARG(x && w && y, "pwv_linear_split_f32: NULL pointer");
+    PWV_CHECK_ARG(M >= 0 && K >= 8 && K % 8 == 0 && K <= 128, "pwv_linear_split_f32: K must be a multiple of 8 in [8,128], got %d", K);
+    PWV_CHECK_ARG(Nout >= 4 && Nout % 4 == 0, "pwv_linear_split_f32: Nout must be a multiple of 4, got %d", Nout);
+    if (M == 0) return PWV_OK;
+    const unsigned gy = (unsigned)((Nout + 127) / 128);
+    unsigned gx = (unsigned)((M + 127) / 128);
+    const unsigned cap = (1024u + gy - 1) / gy;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, gy), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (K <= 64)
+        hipLaunchKernelGGL((linear_split_kernel<4>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    else if (K <= 80)
+        hipLaunchKernelGGL((linear_split_kernel<5>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    else
+        hipLaunchKernelGGL((linear_split_kernel<8>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

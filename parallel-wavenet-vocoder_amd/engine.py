@@ -115,12 +115,15 @@ def causal_conv_op(value: torch.Tensor, filter_: torch.Tensor, dilation: int) ->
     return out
 
 
-def linear_op(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+def linear_op(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
+              precision: Optional[str] = None) -> torch.Tensor:
+    """y = act(x @ w + bias).  precision 'f32': exact fp32 MFMA; otherwise (default) split-fp16 MFMA -- the
+    arithmetic of the fused kernels in the same mode."""
     m, k = x2d.shape
     nout = w.shape[1]
     y = torch.empty((m, nout), dtype=torch.float32, device=x2d.device)
-    check(_lib.lib().pwv_linear_f32(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(y), m, k, nout, int(relu), _stream()),
-          'pwv_linear_f32')
+    fn = _lib.lib().pwv_linear_f32 if (precision or DEFAULT_PRECISION) == 'f32' else _lib.lib().pwv_linear_split_f32
+    check(fn(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(y), m, k, nout, int(relu), _stream()), 'pwv_linear')
     return y
 
 
@@ -303,12 +306,13 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             # net 0's P on the main stream, net 1's on its own stream: its chain then starts one small GEMM
             # later than net 0's, which keeps the two chains out of phase (they would otherwise run in
             # lockstep and hit their launch gaps / tails together)
-            projs = [linear_op(f2d, plans[0].proj_w, plans[0].proj_b, relu=False), None]
+            pname = precision or DEFAULT_PRECISION
+            projs = [linear_op(f2d, plans[0].proj_w, plans[0].proj_b, relu=False, precision=pname), None]
             side[1].wait_stream(main)
             with torch.cuda.stream(side[1]):
-                projs[1] = linear_op(f2d, plans[1].proj_w, plans[1].proj_b, relu=False)
+                projs[1] = linear_op(f2d, plans[1].proj_w, plans[1].proj_b, relu=False, precision=pname)
         else:
-            projs = [linear_op(f2d, p.proj_w, p.proj_b, relu=False) for p in plans]
+            projs = [linear_op(f2d, p.proj_w, p.proj_b, relu=False, precision=precision or DEFAULT_PRECISION) for p in plans]
     else:
         projs = [p.proj_b.reshape(1, -1) for p in plans]
     row_stride = 128 * L

@@ -105,7 +105,7 @@ class IAFVocoder(object):
                 w = get_variable('transposed_conv_{}_weights'.format(i), (1, stride, C, input_channels), store=store)
                 # kernel width == stride: out[t*s + j, co] = sum_ci in[t, ci] * w[0, j, co, ci]  (a GEMM)
                 wmat = w[0].permute(2, 0, 1).reshape(input_channels, stride * C).contiguous()
-                cond = engine.linear_op(cond, wmat, None, relu=True)            # models.py:118-120
+                cond = engine.linear_op(cond, wmat, None, relu=True, precision=self.precision)   # models.py:118-120
                 input_channels = C
                 length *= stride
                 cond = cond.reshape(n * length, C)
@@ -116,7 +116,8 @@ class IAFVocoder(object):
             return engine.crop_time_op(cond, length - hop, hop // 2)            # models.py:124
         elif method == 'repeat':
             w = get_variable('dense', [1, n_mels, C], store=store)
-            frames = engine.linear_op(melspec.reshape(n * t_mel, n_mels), w[0], None, relu=True)   # models.py:128-130
+            frames = engine.linear_op(melspec.reshape(n * t_mel, n_mels), w[0], None, relu=True,
+                                      precision=self.precision)                              # models.py:128-130
             return RepeatedCondition(frames.reshape(n, t_mel, C), hop, hop // 2, self.length)      # models.py:131-133
         return None
 

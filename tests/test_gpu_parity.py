@@ -38,8 +38,10 @@ def test_causal_conv_empty(gpu):
 
 @pytest.mark.parametrize('M,K,Nout,relu,bias', [(201, 80, 80, True, False), (50, 80, 400, True, False),
                                                 (333, 80, 1280, False, True), (7, 64, 36, False, True),
-                                                (129, 128, 132, True, True)])
-def test_linear(gpu, M, K, Nout, relu, bias):
+                                                (129, 128, 132, True, True), (65, 24, 260, False, True),
+                                                (2001, 80, 3840, False, True)])
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_linear(gpu, M, K, Nout, relu, bias, precision):
     from pwv_amd import engine
     rng = np.random.RandomState(1)
     x = rng.randn(M, K).astype(np.float32)
@@ -48,7 +50,7 @@ def test_linear(gpu, M, K, Nout, relu, bias):
     want = x.astype(np.float64) @ w.astype(np.float64) + (b.astype(np.float64) if bias else 0)
     if relu:
         want = np.maximum(want, 0)
-    got = engine.linear_op(_t(x, gpu), _t(w, gpu), _t(b, gpu) if bias else None, relu).cpu().numpy()
+    got = engine.linear_op(_t(x, gpu), _t(w, gpu), _t(b, gpu) if bias else None, relu, precision=precision).cpu().numpy()
     assert np.abs(got - want).max() <= 1e-5
 
 
