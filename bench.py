@@ -55,6 +55,7 @@ def parse_args():
                     help="GEMM arithmetic: f16x3 = 3-term split-fp16 MFMA, fp32 accumulate (default, fp32 parity); f32 = exact "
                          "fp32 MFMA; f16 = REDUCED PRECISION build extension (fp16 residual stream, BASELINE config 5) -- "
                          "never the headline number")
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
     return ap.parse_args()
@@ -145,8 +146,19 @@ def main():
     store.version += 1
     engine.clear_plan_cache()
 
-    def step():
+    def eager_step():
         return model(None, mel, is_training=False)
+
+    if args.no_graph:
+        step = eager_step
+    else:
+        # the same launches, captured once into a HIP graph (pwv_amd/graph.py); each step = one eager noise-sampling
+        # kernel (fresh logistic noise every step) + the mel copy + one graph replay
+        from pwv_amd.graph import GraphedVocoder
+        graphed = GraphedVocoder(model)
+
+        def step():
+            return graphed(mel)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -171,7 +183,7 @@ def main():
     # ---- live kernel timing of the dominant kernel (HIP events on the launch stream) -------------------
     engine.EVENT_LOG = []
     for _ in range(max(1, min(args.steps, 5))):
-        step()
+        eager_step()
     torch.cuda.synchronize()
     log, engine.EVENT_LOG = engine.EVENT_LOG, None
     # each entry: one chain's run of `cnt` back-to-back residual-layer launches between two HIP events
@@ -222,6 +234,7 @@ def main():
                 'case': args.case, 'utterances_per_gpu': utts, 'samples_per_utterance': length,
                 'parallelism': 'utterance-sharded x%d (no data-path collective)' % n_gpus,
                 'noise': 'logistic, sampled on device inside the step',
+                'launch': 'host-enqueued launches' if args.no_graph else 'HIP graph replay of the forward (noise sampled by an eager kernel per step)',
             },
         }
         common = {'avg_launch_ms': layer_ms, 'launches_timed': len(res_ms), 'alg_flop_per_launch': flop_per_launch,

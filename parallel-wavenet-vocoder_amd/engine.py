@@ -134,8 +134,10 @@ def crop_time_op(x: torch.Tensor, t_out: int, offset: int) -> torch.Tensor:
     return out
 
 
-def logistic_noise_op(shape: Sequence[int], device, seed: int, offset: int = 0) -> torch.Tensor:
-    z = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+def logistic_noise_op(shape: Sequence[int], device, seed: int, offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    z = out if out is not None else torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    if out is not None and (tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous()):
+        raise ValueError('out must be a contiguous float32 tensor of shape %s' % (tuple(shape),))
     check(_lib.lib().pwv_logistic_noise_f32(_ptr(z), z.numel(), seed, offset, _stream()), 'pwv_logistic_noise_f32')
     return z
 

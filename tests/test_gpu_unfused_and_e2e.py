@@ -133,3 +133,36 @@ def test_generate_from_wav_files(gpu, tmp_path, monkeypatch):
     assert (logdir / 'pred_0.wav').exists() and (logdir / 'pred_1.wav').exists()
     rate, data = wavfile.read(str(logdir / 'pred_0.wav'))
     assert rate == sr and data.shape == (8000,)
+
+
+def test_graphed_vocoder_matches_eager_bitwise(gpu):
+    """pwv_amd/graph.py: the captured forward is the same launches -> same bits; new inputs go through the static
+    buffers; changing a weight re-captures (the graph would otherwise replay stale packed weights)."""
+    import torch
+    from oracle import iaf_oracle as O
+    from pwv_amd.graph import GraphedVocoder
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    from tests.util import set_hparams, small_cfg
+    cfg = small_cfg()
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=4))
+    n, length = 2, 480
+    model = IAFVocoder(batch_size=n, length=length, store=store)
+    mel_np, z_np = O.synthetic_inputs(n, length, cfg)
+    mel, z = torch.from_numpy(mel_np).to(gpu), torch.from_numpy(z_np).to(gpu)
+    want = model(None, mel, is_training=False, z=z).clone()
+    graphed = GraphedVocoder(model)
+    assert torch.equal(graphed(mel, z=z), want)
+    mel2, z2 = mel * 0.5, z.flip(1).contiguous()
+    assert torch.equal(graphed(mel2, z=z2).clone(), model(None, mel2, is_training=False, z=z2))
+    a = graphed(mel).clone()          # sampled noise: a fresh counter range per call
+    b = graphed(mel).clone()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    name = 'iaf_vocoder/iaf0/scalar/postprocessing/postprocess2_bias'
+    store.assign(name, (store.vars[name] + 0.25).cpu().numpy())
+    got = graphed(mel, z=z).clone()
+    assert torch.equal(got, model(None, mel, is_training=False, z=z)) and not torch.equal(got, want)
+    with pytest.raises(ValueError):
+        graphed(mel[:, :-1])
