@@ -11,11 +11,16 @@ dilated layers, 'repeat' conditioning) on one batch of synthetic input: mel alre
 ("C3"): 1 utterance x 160000 samples (10 s @ 16 kHz, 2001 mel frames x 80
 mels, hop 80) per GPU; utterances shard across GPUs with no data-path collective (weak scaling).
 
+The timed loop replays a HIP graph of the forward (pwv_amd/graph.py; --no-graph enqueues every launch from the
+host); each step samples fresh logistic noise with one eager kernel.
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline      -- the dominant kernel (fused gated-residual layer, G=2 nets per launch): its
-                   algorithmic FLOPs per launch / its average duration measured with HIP events on
-                   the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s); the HBM view
-                   (algorithmic bytes vs 8 TB/s) is reported beside it as roofline_hbm
+  roofline      -- the dominant kernel (fused gated-residual layer): algorithmic bytes (512 B per sample, net and
+                   layer) per launch x concurrent launches / its mean launch duration, measured live with HIP events
+                   the library records on the launch streams around each chain's run of residual-layer launches
+                   (pwv_stack_args.ev_begin / ev_end, production launch path) against 8 TB/s; `traffic` = HBM bytes per
+                   launch from the committed PMC passes (profiles/); the matrix-pipe view is beside it as roofline_mfma
+                   (with --precision f32 the roles swap: fp32 MFMA roofline, HBM view beside it)
   cpu_baseline  -- the oracle's torch-CPU fp32 port of the same model timed on this host's cores
                    on a bounded sample (rank 0, N=1 only); a reported baseline, not the target.
 """
@@ -246,13 +251,13 @@ def main():
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
         # MI355X_MICROARCH.md prescribes) are collected offline and committed under profiles/; quoted here only
         # when they were taken on this exact workload and kernel
-        tpath = os.path.join(ROOT, 'profiles', 'r01_c_hbm_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'r01_d_hbm_traffic.json')
         if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             # the PMC passes count bytes per launch of one net; a G = 2 launch (PWV_TWO_STREAMS=0) moves twice that
             common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
-            common['traffic_source'] = 'profiles/r01_c_hbm_traffic.json'
+            common['traffic_source'] = 'profiles/r01_d_hbm_traffic.json'
         if args.precision == 'f32':
             # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
             result['roofline'] = dict(kernel='layer_f32_kernel<8,0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,

@@ -247,6 +247,12 @@ typedef struct pwv_stack_args {
     int cond_hop, cond_offset, cond_frames;
     int precision;
     int max_workgroups;
+    /* optional timing hooks (hipEvent_t, may be NULL): ev_begin[c] is recorded on chain c's stream in front of its
+     * first layer launch, ev_end[c] behind its last RESIDUAL layer launch (layer n_layers-2) -- elapsed / (n_layers-1)
+     * is the mean launch duration of the dominant kernel on the production launch path (bench.py's roofline).
+     * One chain (c = 0) in single-stream mode, one per net with two streams. */
+    void* ev_begin[PWV_MAX_NETS];
+    void* ev_end[PWV_MAX_NETS];
 } pwv_stack_args;
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);

@@ -91,6 +91,8 @@ class StackArgs(Structure):
         ('cond_hop', c_int), ('cond_offset', c_int), ('cond_frames', c_int),
         ('precision', c_int),
         ('max_workgroups', c_int),
+        ('ev_begin', c_void_p * PWV_MAX_NETS),
+        ('ev_end', c_void_p * PWV_MAX_NETS),
     ]
 
 

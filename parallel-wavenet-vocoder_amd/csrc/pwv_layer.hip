@@ -732,8 +732,10 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
             la.out_mode = last ? PWV_OUT_GATED : PWV_OUT_RESIDUAL;
             la.precision = a->precision;
             la.max_workgroups = wgs;
+            if (j == 0 && a->ev_begin[grp]) PWV_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin[grp], (hipStream_t)streams[grp]));
             const int rc = pwv_wavenet_layer_f32(&la, streams[grp]);
             if (rc != PWV_OK) return rc;
+            if (j == a->n_layers - 2 && a->ev_end[grp]) PWV_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_end[grp], (hipStream_t)streams[grp]));
         }
         cur ^= 1;
     }

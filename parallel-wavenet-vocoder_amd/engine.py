@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import HeadArgs, LayerArgs, StackArgs, check
+from ._lib import StackArgs, check
 
 # 'f32'  : v_mfma_f32_32x32x2_f32, exact fp32 fma chains (157 TFLOP/s class)
 # 'f16x3': 3-term split-fp16 MFMA with fp32 accumulation (w*x ~= wh*xh + wh*xl + wl*xh, ~22-bit
@@ -340,93 +340,43 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     Q = net0.out_channels
     outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
 
-    def launch_layer(group, j, cur, stream, stream_obj, wgs):
-        a = LayerArgs()
-        a.G = len(group)
-        a.proj_row_stride = row_stride
-        a.cond = _ptr(cond_t)
-        a.cond_channels = net0.condition_channels if mode == 'samples' else 0
-        a.N, a.T = n, t
-        a.cond_hop, a.cond_offset, a.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
-        a.precision = prec
-        a.max_workgroups = wgs
-        last = j == L - 1
-        for i, g in enumerate(group):
-            a.x_in[i] = bufs[g][cur].data_ptr()
-            a.x_out[i] = bufs[g][cur ^ 1].data_ptr()
-            a.packed[i] = plans[g].packed_layers[j].data_ptr()
-            a.proj[i] = projs[g].data_ptr() + 4 * 128 * j
-            a.skip[i] = skips[g].data_ptr() if use_skip else None
-        a.skip_init = 1 if j == 0 else 0
-        a.dilation = int(net0.dilations[j])
-        a.out_mode = _lib.OUT_GATED if last else _lib.OUT_RESIDUAL
-        check(lib.pwv_wavenet_layer_f32(ctypes.byref(a), stream), 'pwv_wavenet_layer_f32')
-
-    def launch_head(group, cur, stream, wgs):
-        h = HeadArgs()
-        h.G = len(group)
-        h.N, h.T, h.Q = n, t, Q
-        h.in_mode = _lib.HEAD_IN_SKIPSUM if use_skip else _lib.HEAD_IN_GATED
-        h.precision = prec
-        h.max_workgroups = wgs
-        for i, g in enumerate(group):
-            h.in_[i] = skips[g].data_ptr() if use_skip else bufs[g][cur].data_ptr()
-            h.packed[i] = plans[g].packed_head.data_ptr()
-            h.out[i] = outs[g].data_ptr()
-        check(lib.pwv_wavenet_head_f32(ctypes.byref(h), stream), 'pwv_wavenet_head_f32')
-
-    def run_instrumented(groups, streams, stream_objs, wgs):
-        """Same launch order as pwv_wavenet_stack_f32 (layer j of every group, then j+1, ..., then the heads),
-        one host call per launch.  Each chain's run of residual-layer launches (all but the last layer) is
-        bracketed by ONE pair of HIP events on its own stream: average launch duration = elapsed / launches,
-        without an event between every two kernels (which would perturb what is being measured)."""
-        cur = 0
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
-        for j in range(L):
-            for k, (grp, st, so) in enumerate(zip(groups, streams, stream_objs)):
-                if j == 0 and L > 1:
-                    evs[k][0].record(so)
-                launch_layer(grp, j, cur, st, so, wgs)
-                if j == L - 2:
-                    evs[k][1].record(so)
-                    EVENT_LOG.append(('layer_residual', evs[k][0], evs[k][1], len(grp), L - 1))
-            cur ^= 1
-        for grp, st in zip(groups, streams):
-            launch_head(grp, cur, st, wgs)
-
     if two:
         for g in range(2):
             side[g].wait_stream(main)
-    if EVENT_LOG is not None:
-        # instrumented path (bench.py's live kernel timing)
-        if two:
-            half = max(1, lib.pwv_device_cus() // 2)
-            run_instrumented([[0], [1]], [c_void_p(side[0].cuda_stream), c_void_p(side[1].cuda_stream)], side[:2], half)
-        else:
-            run_instrumented([list(range(G))], [s], [main], max_workgroups)
-    else:
-        # production path: the whole stack + head in ONE C call (interleaved over the two streams)
-        sa = StackArgs()
-        sa.G, sa.n_layers = G, L
-        dil = (ctypes.c_int * L)(*[int(d) for d in net0.dilations])
-        sa.dilations = dil
-        for g in range(G):
-            sa.buf0[g], sa.buf1[g] = bufs[g][0].data_ptr(), bufs[g][1].data_ptr()
-            sa.packed_layers[g] = plans[g].packed_layers.data_ptr()
-            sa.proj[g] = projs[g].data_ptr()
-            sa.skip[g] = skips[g].data_ptr() if use_skip else None
-            sa.packed_head[g] = plans[g].packed_head.data_ptr()
-            sa.out[g] = outs[g].data_ptr()
-        sa.packed_layer_stride = plans[0].layer_floats
-        sa.proj_row_stride = row_stride
-        sa.cond = _ptr(cond_t)
-        sa.cond_channels = net0.condition_channels if mode == 'samples' else 0
-        sa.Q, sa.N, sa.T = Q, n, t
-        sa.cond_hop, sa.cond_offset, sa.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
-        sa.precision = prec
-        sa.max_workgroups = max_workgroups
-        streams = (c_void_p * 2)(side[0].cuda_stream if two else s.value, side[1].cuda_stream if two else None)
-        check(lib.pwv_wavenet_stack_f32(ctypes.byref(sa), streams), 'pwv_wavenet_stack_f32')
+    # the whole stack + head in ONE C call (launches interleaved over the two streams)
+    sa = StackArgs()
+    sa.G, sa.n_layers = G, L
+    dil = (ctypes.c_int * L)(*[int(d) for d in net0.dilations])
+    sa.dilations = dil
+    for g in range(G):
+        sa.buf0[g], sa.buf1[g] = bufs[g][0].data_ptr(), bufs[g][1].data_ptr()
+        sa.packed_layers[g] = plans[g].packed_layers.data_ptr()
+        sa.proj[g] = projs[g].data_ptr()
+        sa.skip[g] = skips[g].data_ptr() if use_skip else None
+        sa.packed_head[g] = plans[g].packed_head.data_ptr()
+        sa.out[g] = outs[g].data_ptr()
+    sa.packed_layer_stride = plans[0].layer_floats
+    sa.proj_row_stride = row_stride
+    sa.cond = _ptr(cond_t)
+    sa.cond_channels = net0.condition_channels if mode == 'samples' else 0
+    sa.Q, sa.N, sa.T = Q, n, t
+    sa.cond_hop, sa.cond_offset, sa.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
+    sa.precision = prec
+    sa.max_workgroups = max_workgroups
+    streams = (c_void_p * 2)(side[0].cuda_stream if two else s.value, side[1].cuda_stream if two else None)
+    evs = []
+    if EVENT_LOG is not None and L > 1:
+        # bench.py's live kernel timing: the library records one event pair per chain around its run of residual-layer
+        # launches (pwv_stack_args.ev_begin / ev_end) -- the production launch path plus two event records
+        for c, so in enumerate(side[:2] if two else [main]):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(so)       # materialises the hipEvent_t handles; the library re-records them
+            e1.record(so)
+            sa.ev_begin[c], sa.ev_end[c] = e0.cuda_event, e1.cuda_event
+            evs.append((e0, e1))
+    check(lib.pwv_wavenet_stack_f32(ctypes.byref(sa), streams), 'pwv_wavenet_stack_f32')
+    for e0, e1 in evs:
+        EVENT_LOG.append(('layer_residual', e0, e1, 1 if two else G, L - 1))
     if two:
         for g in range(2):
             main.wait_stream(side[g])
