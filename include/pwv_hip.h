@@ -133,6 +133,12 @@ int pwv_iaf_front_f16(const float* z, const float* s, const float* b, int sb_str
  * (10 chunks per row, same channel order), pwv_tile32_floats(rows, 80) halfs */
 int pwv_cond_to_f16(const float* cond, void* out16, int N, int T, int C, pwv_stream_t stream);
 
+/* PWV_PREC_F16X3: the same conversion plus the `lo` plane fp16(v - fp16(v)) stored behind the `hi` plane
+ * (2 x pwv_tile32_floats(rows, 80) halfs in total): the split-fp16 layer kernel reads both operands of its
+ * condition GEMM from these planes (the condition is constant over the 120 net-layers of a forward, so it is
+ * split once instead of 120 times) */
+int pwv_cond_split_f16(const float* cond, void* out16, int N, int T, int C, pwv_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Fused gated-residual layer: WaveNet._create_dilation_layer          modules.py:185-259
  * for R = D = 64, S = 128, filter_width 2 (hparams/default.yaml:22-25), G <= 2 nets per launch.
@@ -147,7 +153,8 @@ int pwv_cond_to_f16(const float* cond, void* out16, int N, int T, int C, pwv_str
  * filter_bias‖gate_bias, in the kernel's column order (pwv_proj_column_map); the row used by
  * sample t of utterance n is  n*cond_frames + (t + cond_offset)/cond_hop  (cond_hop == 0:
  * always row 0, i.e. biases only / no conditioning).  `cond` (per-sample condition, 80 channels,
- * transposed-conv upsampling; tile32) is NULL in hoisted mode.
+ * transposed-conv upsampling) is NULL in hoisted mode; its form depends on `precision`: fp32 tile32
+ * (PWV_PREC_F32), pwv_cond_split_f16 planes (PWV_PREC_F16X3), pwv_cond_to_f16 blocks (PWV_PREC_F16).
  * ------------------------------------------------------------------------------------- */
 #define PWV_OUT_RESIDUAL 0
 #define PWV_OUT_GATED 1
@@ -174,7 +181,7 @@ typedef struct pwv_layer_args {
     const float* packed[PWV_MAX_NETS];     /* pwv_pack_layer_f32 output */
     const float* proj[PWV_MAX_NETS];       /* P rows for THIS layer (128 floats each) */
     int proj_row_stride;                   /* floats between consecutive P rows */
-    const float* cond;                     /* tile32, N*T rows x cond_channels, or NULL */
+    const float* cond;                     /* per-sample condition in the form `precision` wants, or NULL */
     int cond_channels;                     /* 0 or 80 */
     float* skip[PWV_MAX_NETS];             /* tile32, N*T rows x 128: accumulators, or NULL */
     int skip_init;                         /* 1: skip = ..., 0: skip += ... */
@@ -237,7 +244,7 @@ typedef struct pwv_stack_args {
     size_t packed_layer_stride;                   /* floats between consecutive layers */
     const float* proj[PWV_MAX_NETS];              /* P rows holding all layers: layer j at +128*j */
     int proj_row_stride;
-    const float* cond;                            /* tile32, N*T rows x cond_channels, or NULL */
+    const float* cond;                            /* per-sample condition in the form `precision` wants, or NULL */
     int cond_channels;
     float* skip[PWV_MAX_NETS];                    /* tile32, N*T rows x 128, or NULL (use_skip_connection) */
     const float* packed_head[PWV_MAX_NETS];

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
-    'pwv_linear_split_f32',
+    'pwv_linear_split_f32', 'pwv_cond_split_f16',
 )
 
 
@@ -135,6 +135,7 @@ def _declare(lib):
                                       c_int, c_int, c_int, c_int, c_void_p]
     lib.pwv_iaf_front_f16.argtypes = lib.pwv_iaf_front_f32.argtypes
     lib.pwv_cond_to_f16.argtypes = [f32p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.pwv_cond_split_f16.argtypes = lib.pwv_cond_to_f16.argtypes
     lib.pwv_tile32_floats.restype = c_size_t
     lib.pwv_tile32_floats.argtypes = [c_int64, c_int]
     lib.pwv_rows_to_tile32_f32.argtypes = [f32p, f32p, c_int64, c_int, c_void_p]

@@ -187,13 +187,16 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         }
         f16x8 ch[5], cl[5];      // per-sample condition, K = 80
         if constexpr (COND) {
-            float cd[40];
-            load_tiled<10, kCondC>(p.cond, rc, h, true, cd);
-            split8<0>(cd, ch[0], cl[0]);
-            split8<8>(cd, ch[1], cl[1]);
-            split8<16>(cd, ch[2], cl[2]);
-            split8<24>(cd, ch[3], cl[3]);
-            split8<32>(cd, ch[4], cl[4]);
+            // pre-split fp16 planes (pwv_cond_split_f16): [hi | lo], each tile32-style [10 chunks][32 rows][8 halfs];
+            // chunk 2s + h is this lane's B operand of k-step s
+            const _Float16* c16 = reinterpret_cast<const _Float16*>(p.cond);
+            const _Float16* cr = c16 + (size_t)(rc >> 5) * (32 * kCondC) + (h * 32 + (rc & 31)) * 8;
+            const size_t plane = tile32_floats(rows, kCondC);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                ch[s] = *reinterpret_cast<const f16x8*>(cr + s * 512);
+                cl[s] = *reinterpret_cast<const f16x8*>(cr + plane + s * 512);
+            }
         }
         PWV_STAMP(1);
 #ifdef PWV_TRACE

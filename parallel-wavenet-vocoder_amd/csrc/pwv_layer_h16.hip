@@ -318,8 +318,11 @@ __global__ __launch_bounds__(256) void iaf_front_h16_kernel(const FrontH16Params
     }
 }
 
-// [N,T,80] fp32 per-sample condition -> fp16 rows in the B-operand order (5 k-steps)
-__global__ void cond_to_h16_kernel(const float* __restrict__ cond, _Float16* __restrict__ out, unsigned rows) {
+// [N,T,80] fp32 per-sample condition -> fp16 tile32 blocks in the B-operand order (5 k-steps); SPLIT adds the
+// `lo` plane fp16(v - fp16(v)) behind the `hi` plane (plane_halfs apart) for the split-fp16 layer kernel, which
+// then reads both operands of its condition GEMM straight from HBM instead of splitting 40 floats per unit
+template <bool SPLIT>
+__global__ void cond_to_h16_kernel(const float* __restrict__ cond, _Float16* __restrict__ out, unsigned rows, size_t plane_halfs) {
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // (block, chunk 0..9, row in block)
     const unsigned row = (idx / 320u) * 32u + (idx & 31u), chunk = (idx >> 5) % 10u;
     if (row >= rows) return;
@@ -327,7 +330,14 @@ __global__ void cond_to_h16_kernel(const float* __restrict__ cond, _Float16* __r
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = cond[(size_t)row * kCondC + 16 * s + 8 * (q >> 2) + 4 * h + (q & 3)];
-    *reinterpret_cast<f16x8*>(out + xoff((int)row, (int)chunk, kCondC)) = to_h8<0>(v);
+    const f16x8 hi = to_h8<0>(v);
+    *reinterpret_cast<f16x8*>(out + xoff((int)row, (int)chunk, kCondC)) = hi;
+    if constexpr (SPLIT) {
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = v[q] - (float)hi[q];
+        *reinterpret_cast<f16x8*>(out + plane_halfs + xoff((int)row, (int)chunk, kCondC)) = to_h8<0>(r);
+    }
 }
 
 int launch_layer_h16(const LayerParams& lp, bool cond, bool gated, int per_net, hipStream_t s) {
@@ -390,8 +400,19 @@ int pwv_cond_to_f16(const float* cond, void* out16, int N, int T, int C, pwv_str
     const long long total = ((long long)N * T + 31) / 32 * 32 * 10;
     PWV_CHECK_ARG(N >= 0 && T >= 0 && total < (1ll << 31), "pwv_cond_to_f16: bad size");
     if (total == 0) return PWV_OK;
-    hipLaunchKernelGGL(cond_to_h16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cond,
-                       reinterpret_cast<_Float16*>(out16), (unsigned)(N * T));
+    hipLaunchKernelGGL(cond_to_h16_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cond,
+                       reinterpret_cast<_Float16*>(out16), (unsigned)(N * T), (size_t)0);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_cond_split_f16(const float* cond, void* out16, int N, int T, int C, pwv_stream_t stream) {
+    PWV_CHECK_ARG(cond && out16 && C == kCondC, "pwv_cond_split_f16: NULL pointer or C != %d", kCondC);
+    const long long total = ((long long)N * T + 31) / 32 * 32 * 10;
+    PWV_CHECK_ARG(N >= 0 && T >= 0 && total < (1ll << 31), "pwv_cond_split_f16: bad size");
+    if (total == 0) return PWV_OK;
+    hipLaunchKernelGGL(cond_to_h16_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cond,
+                       reinterpret_cast<_Float16*>(out16), (unsigned)(N * T), tile32_floats((long long)N * T, kCondC));
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

@@ -207,7 +207,7 @@ class NetPlan:
 
 
 _plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
-_cond_cache = None      # (weakref(condition tensor), its version, fp16?, tile32 copy, stream it was made on)
+_cond_cache = None      # (weakref(condition tensor), its version, precision, converted copy, stream it was made on)
 
 
 def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
@@ -280,22 +280,28 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     def tile_buf(channels, dtype=torch.float32):
         return torch.empty((lib.pwv_tile32_floats(rows, channels),), dtype=dtype, device=dev)
 
-    if cond_t is not None:      # per-sample condition -> tile32 (fp16 blocks in 'f16' mode)
-        # every flow of a forward pass is handed the same tensor: convert it once (the entry is valid while that
+    if cond_t is not None:
+        # per-sample condition -> the form the kernels of this precision read: fp32 tile32 ('f32'), pre-split fp16
+        # hi / lo planes ('f16x3': split once per forward instead of once per net-layer), fp16 blocks ('f16').
+        # Every flow of a forward pass is handed the same tensor: convert it once (the entry is valid while that
         # very tensor object is alive and has not been written to)
         global _cond_cache
         hit = _cond_cache
-        if (hit is not None and hit[0]() is cond_t and hit[1] == cond_t._version and hit[2] == half
+        if (hit is not None and hit[0]() is cond_t and hit[1] == cond_t._version and hit[2] == prec
                 and hit[4] == torch.cuda.current_stream()):
             cond_t = hit[3]
         else:
             cc = cond_t.shape[2]
-            ct = tile_buf(cc, torch.float16 if half else torch.float32)
-            if half:
-                check(lib.pwv_cond_to_f16(_ptr(cond_t), _ptr(ct), n, t, cc, s), 'pwv_cond_to_f16')
-            else:
+            if prec == _lib.PREC_F32:
+                ct = tile_buf(cc)
                 check(lib.pwv_rows_to_tile32_f32(_ptr(cond_t), _ptr(ct), rows, cc, s), 'pwv_rows_to_tile32_f32')
-            _cond_cache = (weakref.ref(cond_t), cond_t._version, half, ct, torch.cuda.current_stream())
+            elif prec == _lib.PREC_F16X3:
+                ct = torch.empty((2 * lib.pwv_tile32_floats(rows, cc),), dtype=torch.float16, device=dev)
+                check(lib.pwv_cond_split_f16(_ptr(cond_t), _ptr(ct), n, t, cc, s), 'pwv_cond_split_f16')
+            else:
+                ct = tile_buf(cc, torch.float16)
+                check(lib.pwv_cond_to_f16(_ptr(cond_t), _ptr(ct), n, t, cc, s), 'pwv_cond_to_f16')
+            _cond_cache = (weakref.ref(cond_t), cond_t._version, prec, ct, torch.cuda.current_stream())
             cond_t = ct
 
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
