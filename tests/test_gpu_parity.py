@@ -294,3 +294,26 @@ def test_sample_condition_cache_sees_in_place_updates(gpu):
     y1 = net(x, cond)
     assert not torch.equal(y1, y0)
     assert torch.equal(net(x, cond.clone()), y1)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_vocoder_random_configurations(gpu, seed):
+    """Seeded sweep over the structural switches of the path (flows, dilation lists incl. d > T, biases, skip
+    accumulation, shared nets, repeat / transposed-conv / no conditioning, batch, length, both arithmetics):
+    every draw must meet the fp32 bar against the fp64 oracle."""
+    rng = np.random.RandomState(1000 + seed)
+    n_iaf = int(rng.randint(1, 3))
+    dil = [[int(2 ** rng.randint(0, 10)) for _ in range(rng.randint(1, 6))] for _ in range(n_iaf)]
+    method = ['repeat', 'transposed_conv', 'none'][int(rng.randint(0, 3))]
+    shared = bool(rng.randint(0, 2))
+    cfg = O.ModelConfig(dilations=dil, n_iaf=n_iaf, use_biases=bool(rng.randint(0, 2)),
+                        use_skip_connection=bool(rng.randint(0, 2)), cond_upsample_method=method, shared_nets=shared)
+    weights = O.init_weights(cfg, seed=int(rng.randint(0, 1 << 20)))
+    n, length = int(rng.randint(1, 4)), 80 * int(rng.randint(1, 7))
+    mel, z = O.synthetic_inputs(n, length, cfg, mel_seed=seed, z_seed=seed + 100)
+    want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+    precision = ['f32', 'f16x3'][seed % 2]
+    got = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = np.abs(got - want).max()
+    assert got.shape == want.shape and err <= TOL_F32 * scale, (err, scale, dil, method, shared, precision)
