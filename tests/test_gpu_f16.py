@@ -173,3 +173,22 @@ def test_f16_shallow_net_matches_fp16_storage_model(gpu):
     exact = O.wavenet_forward(w, 'iaf_vocoder/iaf0/scalar', xn, None, dilations=dil, use_biases=True,
                               use_skip_connection=False)
     assert np.abs(got - model).max() <= 3e-4 and np.abs(got - exact).max() <= TOL_F16
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_f16_random_configurations(gpu, seed):
+    """The structural sweep of test_gpu_parity.py::test_vocoder_random_configurations in the fp16 mode (no skip
+    accumulation there): within the stated fp16 bar of the fp64 oracle, relative to the output scale."""
+    rng = np.random.RandomState(2000 + seed)
+    n_iaf = int(rng.randint(1, 3))
+    dil = [[int(2 ** rng.randint(0, 10)) for _ in range(rng.randint(1, 6))] for _ in range(n_iaf)]
+    method = ['repeat', 'transposed_conv', 'none'][int(rng.randint(0, 3))]
+    cfg = O.ModelConfig(dilations=dil, n_iaf=n_iaf, use_biases=bool(rng.randint(0, 2)), use_skip_connection=False,
+                        cond_upsample_method=method, shared_nets=bool(rng.randint(0, 2)))
+    w = O.init_weights(cfg, seed=int(rng.randint(0, 1 << 20)))
+    n, length = int(rng.randint(1, 4)), 80 * int(rng.randint(1, 7))
+    mel, z = O.synthetic_inputs(n, length, cfg, mel_seed=seed, z_seed=seed + 100)
+    want = O.iaf_vocoder_forward(w, mel, z, cfg)
+    got = run_vocoder_hip(cfg, w, mel, z, gpu, precision='f16')
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= TOL_F16 * scale, (np.abs(got - want).max(), scale, dil, method)
