@@ -9,8 +9,11 @@
  * INTEGRATION.md shows the stub a maintainer of the reference would add.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer owned by the caller (never retained or freed here),
- *     float32, channels-last [N, T, C]; TensorFlow weight layout [width, Cin, Cout];
+ *   - every pointer is a DEVICE pointer owned by the caller (never retained or freed here);
+ *     tensors that cross the boundary (mel, z, waveform, weights, the inputs / outputs of the
+ *     standalone ops) are float32, channels-last [N, T, C], weights in TensorFlow layout
+ *     [width, Cin, Cout]; the scratch activations BETWEEN the fused kernels use the 32-row tiled
+ *     layout "tile32" documented below;
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
  *     (no hidden synchronisation, no internal streams or threads; re-entrant per stream);
  *   - return 0 on success, a negative PWV_E* code otherwise; pwv_last_error() returns a
