@@ -160,10 +160,16 @@ def main():
         # the same launches, captured once into a HIP graph (pwv_amd/graph.py); each step = one eager noise-sampling
         # kernel (fresh logistic noise every step) + the mel copy + one graph replay
         from pwv_amd.graph import GraphedVocoder
-        graphed = GraphedVocoder(model)
+        try:
+            graphed = GraphedVocoder(model)
 
-        def step():
-            return graphed(mel)
+            def step():
+                return graphed(mel)
+        except Exception as e:      # never lose the measurement to a capture problem: same launches, host-enqueued
+            sys.stderr.write('graph capture failed (%s: %s); falling back to host-enqueued launches\n' % (type(e).__name__, e))
+            args.no_graph = True
+            torch.cuda.synchronize()
+            step = eager_step
 
     def sync_all():
         torch.cuda.synchronize()

@@ -50,7 +50,9 @@ class GraphedVocoder(object):
                 self.model(None, self.mel, is_training=False, z=self.z)
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: only this thread's calls are policed during capture (an RCCL watchdog thread of a multi-rank
+        # job may touch the runtime meanwhile); everything captured here is enqueued from this thread
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = self.model(None, self.mel, is_training=False, z=self.z)
         self._version = self.store.version
 
