@@ -108,8 +108,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback exists in the product path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # PWV_BENCH_DRYRUN_ONE_GPU=1 (test hook, tests/test_gpu_unfused_and_e2e.py): all ranks share GPU 0 and rendezvous over
+    # gloo, to exercise the multi-rank control flow (build / barrier / max-over-ranks / rank-0 JSON) on a 1-GPU box
+    dryrun = os.environ.get('PWV_BENCH_DRYRUN_ONE_GPU') == '1'
+    dev_index = 0 if dryrun else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         # keep stdout to the one JSON line: RCCL's version banner (NCCL_DEBUG=VERSION/INFO) would land there
@@ -117,7 +121,10 @@ def main():
             os.environ['NCCL_DEBUG'] = 'WARN'
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)       # RCCL over xGMI
+        if dryrun:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=dev)       # RCCL over xGMI
     n_gpus = world
 
     from oracle.iaf_oracle import ModelConfig
@@ -186,7 +193,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dryrun else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all(), 'non-finite output'
