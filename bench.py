@@ -95,9 +95,43 @@ def cpu_baseline(case_cfg, target_s):
     iaf_vocoder_forward_torch(w, mel, z, case_cfg)
     dt = time.perf_counter() - t0
     torch.set_num_threads(max_threads)
+    cpu_model = 'unknown CPU'
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+    except Exception:
+        pass
     return {'value': length / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
             'sample': 'same model, 1 utterance x %d samples (%.1f s CPU), torch-CPU fp32 restatement (oracle/torch_cpu.py), '
-                      'best of {%d, %d, 32, 16} threads = %d' % (length, dt, max_threads, max_threads // 2, cores)}
+                      'best of {%d, %d, 32, 16} threads = %d on %s' % (length, dt, max_threads, max_threads // 2, cores, cpu_model)}
+
+
+def model_algorithmic_work(hp, elem_bytes):
+    """SURVEY.md section 8d, the whole-model "layer-streaming" figures: every dilated layer reads its residual stream once
+    and writes it once (halo re-reads, weights and anything a fusion keeps on chip not counted); FLOPs with the
+    conditioning projection hoisted to frame rate in 'repeat' mode; only live ops (skip on the last layer only, no dense
+    on the last layer -- what `use_skip_connection: False` executes)."""
+    m = hp.model
+    W, R, D, S, C = m.filter_width, m.residual_channels, m.dilation_channels, m.skip_channels, m.condition_channels
+    hop, n_mels = hp.signal.hop_length, hp.signal.n_mels
+    shared = bool(m.get('shared_nets', False))
+    Q = 2 if shared else 1
+    nets = []
+    for i in range(m.n_iaf):
+        nets += [len(m.dilations[i])] * (1 if shared else 2)
+    method = m.cond_upsample_method
+    b = elem_bytes
+    cond_b = {'repeat': 2.0 * D * b / hop, 'transposed_conv': float(C * b)}.get(method, 0.0)
+    nbytes = sum((L - 1) * 2 * R * b + 2 * b + L * cond_b for L in nets)
+    per_sample_cond = 2 * C * D if method == 'transposed_conv' else 0
+    mac = 0
+    for L in nets:
+        skip_all = bool(m.use_skip_connection)
+        layers = sum(2 * W * R * D + per_sample_cond + (D * S if (j == L - 1 or skip_all) else 0) + (D * R if j < L - 1 or skip_all else 0)
+                     for j in range(L))
+        mac += W * 1 * R + layers + S * S + S * Q
+    mac += {'repeat': n_mels * C / hop, 'transposed_conv': 8000.0}.get(method, 0.0)
+    return nbytes, 2.0 * mac
 
 
 def main():
@@ -292,6 +326,15 @@ def main():
                                       frac=ach_gbs / PEAK_HBM_GBS, **common)
             result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
                                        'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
+        mb, mf = model_algorithmic_work(hp, 2 if args.precision == 'f16' else 4)
+        per_gpu = value / n_gpus
+        result['model'] = {
+            'note': 'whole-model algorithmic work per output sample (SURVEY.md section 8d "layer-streaming" model), per GPU',
+            'alg_bytes_per_sample': mb, 'alg_flop_per_sample': mf,
+            'hbm_GBs': mb * per_gpu / 1e9, 'hbm_frac_of_8TBs': mb * per_gpu / 1e9 / PEAK_HBM_GBS,
+            'alg_TFLOPs': mf * per_gpu / 1e12,
+            'vs_fp32_fma_ceiling': per_gpu / (PEAK_F32_MFMA_TFLOPS * 1e12 / mf),
+        }
         if n_gpus == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(ModelConfig.from_hparam(hp), args.cpu_seconds)
         sys.stdout.flush()
