@@ -66,3 +66,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.PwvError, match='no CPU fallback'):
         _lib.lib()
+
+
+def test_header_is_plain_c():
+    """include/pwv_hip.h is the drop-in boundary: it must compile as C99 (no C++ / torch / HIP types in it), and the
+    ctypes mirrors in _lib.py must have the sizes the C compiler gives the structs."""
+    import ctypes
+    import os
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ('#include <stdio.h>\n#include "pwv_hip.h"\nint main(void){ printf("%zu %zu %zu\\n", sizeof(pwv_layer_args), '
+           'sizeof(pwv_head_args), sizeof(pwv_stack_args)); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, 't.c'), os.path.join(d, 't')
+        with open(c, 'w') as f:
+            f.write(src)
+        subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I' + os.path.join(root, 'include'), c, '-o', exe])
+        sizes = [int(x) for x in re.findall(r'\d+', subprocess.check_output([exe]).decode())]
+    from pwv_amd import _lib
+    assert sizes == [ctypes.sizeof(_lib.LayerArgs), ctypes.sizeof(_lib.HeadArgs), ctypes.sizeof(_lib.StackArgs)]
