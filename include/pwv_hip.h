@@ -193,6 +193,13 @@ typedef struct pwv_layer_args {
     int out_mode;                          /* PWV_OUT_RESIDUAL / PWV_OUT_GATED */
     int precision;                         /* PWV_PREC_* */
     int max_workgroups;                    /* 0 = one per CU */
+    /* Layer 0 of a scalar-input net without a materialised causal layer (PWV_PREC_F16X3, no skip accumulation,
+     * filter width 2): when x_first != NULL, x_in is ignored and the kernel evaluates
+     *     h[t] = x_first[t-1] * causal_filter[0,0,:] + x_first[t] * causal_filter[1,0,:]      modules.py:179-180
+     * for rows t and t-d itself, with the operations (and bits) of pwv_iaf_front_f32: 4 B instead of 768 B of
+     * traffic per sample for this layer and no front launch.  x_first is [N*T] float32 (the flow's input). */
+    const float* x_first;
+    const float* causal_filter[PWV_MAX_NETS];   /* [2,1,64] each */
 } pwv_layer_args;
 
 int pwv_wavenet_layer_f32(const pwv_layer_args* args, pwv_stream_t stream);
@@ -263,6 +270,10 @@ typedef struct pwv_stack_args {
      * One chain (c = 0) in single-stream mode, one per net with two streams. */
     void* ev_begin[PWV_MAX_NETS];
     void* ev_end[PWV_MAX_NETS];
+    /* optional: layer 0 evaluates the causal layer itself (see pwv_layer_args.x_first); buf0 then only serves as the
+     * ping-pong partner of buf1 and need not be initialised */
+    const float* x_first;
+    const float* causal_filter[PWV_MAX_NETS];
 } pwv_stack_args;
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);

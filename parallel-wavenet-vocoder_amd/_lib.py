@@ -54,6 +54,8 @@ class LayerArgs(Structure):
         ('out_mode', c_int),
         ('precision', c_int),
         ('max_workgroups', c_int),
+        ('x_first', c_void_p),
+        ('causal_filter', c_void_p * PWV_MAX_NETS),
     ]
 
 
@@ -93,6 +95,8 @@ class StackArgs(Structure):
         ('max_workgroups', c_int),
         ('ev_begin', c_void_p * PWV_MAX_NETS),
         ('ev_end', c_void_p * PWV_MAX_NETS),
+        ('x_first', c_void_p),
+        ('causal_filter', c_void_p * PWV_MAX_NETS),
     ]
 
 

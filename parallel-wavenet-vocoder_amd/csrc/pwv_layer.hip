@@ -593,8 +593,10 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     LayerParams lp{};
     bool any_skip = false;
     for (int g = 0; g < a->G; ++g) {
-        PWV_CHECK_ARG(a->x_in[g] && a->x_out[g] && a->packed[g] && a->proj[g],
+        PWV_CHECK_ARG((a->x_in[g] || a->x_first) && a->x_out[g] && a->packed[g] && a->proj[g],
                       "pwv_wavenet_layer_f32: NULL buffer for net %d", g);
+        PWV_CHECK_ARG(!a->x_first || a->causal_filter[g], "pwv_wavenet_layer_f32: x_first needs causal_filter for net %d", g);
+        lp.cfilt[g] = a->causal_filter[g];
         PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_layer_f32: in-place layers are not supported (x[t-d] halo)");
         lp.x_in[g] = a->x_in[g];
         lp.x_out[g] = a->x_out[g];
@@ -605,6 +607,8 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     }
     for (int g = 0; g < a->G; ++g)
         PWV_CHECK_ARG(!any_skip || a->skip[g], "pwv_wavenet_layer_f32: skip must be set for all nets or none");
+    PWV_CHECK_ARG(!a->x_first || a->precision == PWV_PREC_F16X3, "pwv_wavenet_layer_f32: x_first is implemented for PWV_PREC_F16X3 only");
+    lp.x_first = a->x_first;
     lp.cond = a->cond;
     lp.proj_row_stride = a->proj_row_stride;
     lp.G = a->G;
@@ -732,6 +736,10 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
             la.out_mode = last ? PWV_OUT_GATED : PWV_OUT_RESIDUAL;
             la.precision = a->precision;
             la.max_workgroups = wgs;
+            if (j == 0 && a->x_first) {
+                la.x_first = a->x_first;
+                for (int i = 0; i < per_group; ++i) la.causal_filter[i] = a->causal_filter[two ? grp : i];
+            }
             if (j == 0 && a->ev_begin[grp]) PWV_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin[grp], (hipStream_t)streams[grp]));
             const int rc = pwv_wavenet_layer_f32(&la, streams[grp]);
             if (rc != PWV_OK) return rc;

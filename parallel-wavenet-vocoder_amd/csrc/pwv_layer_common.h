@@ -47,6 +47,8 @@ struct LayerParams {
     unsigned T_magic, T_shift;      // n / T  == umulhi(n, T_magic) >> T_shift   (T_magic == 0: T == 1)
     unsigned hop_magic, hop_shift;  // same for cond_hop
     long long* trace;   // debug builds only (-DPWV_TRACE): per-wave phase timestamps
+    const float* x_first;                   // layer 0 without a materialised causal layer: the scalar input [rows] ...
+    const float* cfilt[PWV_MAX_NETS];       // ... and each net's causal filter [2,1,64] (split-fp16 kernel only)
 };
 
 // exact n / d for n < 2^31 (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l) / d), shift = l - 1

@@ -92,11 +92,17 @@ __device__ __forceinline__ void first_frags(const f16x8* A, int lane, f16x8 (&h)
 // --------------------------------------------------------------------------------------
 // fused gated-residual layer, split-fp16 arithmetic (8 waves, dynamic 32-sample units)
 // --------------------------------------------------------------------------------------
-template <bool SKIP, bool COND, bool GATED>
+// FIRST: layer 0 of a scalar-input net WITHOUT a materialised causal layer.  h[t] = x[t-1] w0 + x[t] w1
+// (modules.py:179-180) is a rank-2 function of two scalars per row, so instead of writing [rows, 64] floats in a
+// front kernel and reading them back twice (x[t], x[t-d]), the lane rebuilds its 32 channels of both rows from four
+// scalars with the same two fp32 operations per channel the front kernel uses (bit-identical): 4 B instead of 768 B of
+// traffic per sample for this layer, and no front launch.
+template <bool SKIP, bool COND, bool GATED, bool FIRST = false>
 __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     constexpr int WAVES = 8;
     constexpr int kLds = layer_floats(SKIP, COND);
-    __shared__ __attribute__((aligned(16))) float lds[kLds + 4];
+    constexpr int kCF = kLds + 4;           // FIRST: the causal filter [2][64] behind the unit counter
+    __shared__ __attribute__((aligned(16))) float lds[kLds + 4 + (FIRST ? 128 : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -143,6 +149,16 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         bool valid;
         unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
         const bool has_prev = t >= p.dilation;
+        if constexpr (FIRST) {
+            // the four scalars the two rows are functions of: x[t], x[t-1], x[t-d], x[t-d-1] (zero left of the start)
+            const float* x1 = p.x_first;
+            const int d = p.dilation;
+            xc[0] = x1[rc];
+            xc[1] = t >= 1 ? x1[rc - (t >= 1 ? 1 : 0)] : 0.f;
+            xb[0] = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f;
+            xb[1] = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
+            return;
+        }
         load_tiled<8, 64>(p.x_in[net], rc, h, true, xc);
         if (__all(has_prev)) {      // wave-uniform fast path: no per-register select
             load_tiled<8, 64>(p.x_in[net], rc - p.dilation, h, true, xb);
@@ -156,6 +172,9 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     int unit = u_begin + wave;
     float rxb[32], rxc[32];      // raw rows of the current unit (prefetched during the previous unit's GEMM2)
     load_x(unit, rxb, rxc);      // in flight while the weights are staged
+    if constexpr (FIRST) {
+        if (tid < 128) lds[kCF + tid] = p.cfilt[net][tid];
+    }
     fill_lds_dma<kLds / 4, WAVES>(lds, p.packed[net], wave, lane);
     __syncthreads();
 #ifdef PWV_TRACE
@@ -203,6 +222,23 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         PWV_STAMP(2);
+        if constexpr (FIRST) {
+            // rebuild this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; same operation order
+            // as iaf_front_kernel: round(x[t-1] w0), then fma(x[t], w1, .)
+            const float x0 = rxc[0], x1v = rxc[1], xd0 = rxb[0], xd1 = rxb[1];
+            const bool has_prev = t >= p.dilation;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCF + 8 * g + 4 * h]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&lds[kCF + 64 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rxc[4 * g + e] = fmaf(x0, w1[e], x1v * w0[e]);
+                    const float vb = fmaf(xd0, w1[e], xd1 * w0[e]);
+                    rxb[4 * g + e] = has_prev ? vb : 0.f;
+                }
+            }
+        }
         f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
         float xc[32];
 #pragma unroll
@@ -646,9 +682,9 @@ __global__ void pack_head_f16_kernel(const float* skip, const float* skip_bias, 
     if (base * 4 < total_floats) o32[base] = v;
 }
 
-template <bool SKIP, bool COND, bool GATED>
+template <bool SKIP, bool COND, bool GATED, bool FIRST = false>
 static int launch16(const LayerParams& lp, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED>), dim3(grid), dim3(512), 0, s, lp);
+    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED, FIRST>), dim3(grid), dim3(512), 0, s, lp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 layer kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
@@ -656,6 +692,11 @@ static int launch16(const LayerParams& lp, int grid, hipStream_t s) {
 
 int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, int per_net, hipStream_t s) {
     const int grid = per_net * lp.G;
+    if (lp.x_first) {
+        if (skip) return set_error(PWV_EINVAL, "x_first (layer 0 without a materialised causal layer) does not support skip accumulation");
+        if (cond) return gated ? launch16<false, true, true, true>(lp, grid, s) : launch16<false, true, false, true>(lp, grid, s);
+        return gated ? launch16<false, false, true, true>(lp, grid, s) : launch16<false, false, false, true>(lp, grid, s);
+    }
     if (skip) {
         if (cond) return gated ? launch16<true, true, true>(lp, grid, s) : launch16<true, true, false>(lp, grid, s);
         return gated ? launch16<true, false, true>(lp, grid, s) : launch16<true, false, false>(lp, grid, s);

@@ -317,3 +317,20 @@ def test_vocoder_random_configurations(gpu, seed):
     scale = max(1.0, float(np.abs(want).max()))
     err = np.abs(got - want).max()
     assert got.shape == want.shape and err <= TOL_F32 * scale, (err, scale, dil, method, shared, precision)
+
+
+@pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
+def test_layer0_rebuilding_the_causal_layer_is_bit_identical(gpu, method, monkeypatch):
+    """Split-fp16 path: layer 0 rebuilds h[t] = x[t-1] w0 + x[t] w1 from the scalar input (pwv_layer_args.x_first)
+    with the front kernel's own two fp32 operations per channel -- switching the front kernel back on must not change
+    a single bit (ragged length, several utterances, dilation of layer 0 > 1 in the second flow, a one-layer net)."""
+    from pwv_amd import engine
+    cfg = O.ModelConfig(dilations=[[1, 2, 4], [4, 1, 8, 2], [2]], n_iaf=3, cond_upsample_method=method)
+    weights = O.init_weights(cfg, seed=21)
+    mel, z = O.synthetic_inputs(3, 80 * 7, cfg)
+    monkeypatch.setattr(engine, 'FUSE_FIRST', True)
+    a = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+    monkeypatch.setattr(engine, 'FUSE_FIRST', False)
+    b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+    assert np.array_equal(a, b)
+    assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
