@@ -200,6 +200,12 @@ typedef struct pwv_layer_args {
      * traffic per sample for this layer and no front launch.  x_first is [N*T] float32 (the flow's input). */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];   /* [2,1,64] each */
+    /* The LAST layer with the post-processing head fused behind it (PWV_PREC_F16X3, out_mode PWV_OUT_GATED, no skip
+     * accumulation, no per-sample condition): when head_packed[g] != NULL the gated output stays in registers and
+     * feeds pwv_wavenet_head_f32's arithmetic directly; head_out[g] receives [N,T,head_q]; x_out is not written. */
+    const float* head_packed[PWV_MAX_NETS];     /* pwv_pack_head_f32 output */
+    float* head_out[PWV_MAX_NETS];
+    int head_q;
 } pwv_layer_args;
 
 int pwv_wavenet_layer_f32(const pwv_layer_args* args, pwv_stream_t stream);
@@ -239,6 +245,8 @@ int pwv_wavenet_head_f32(const pwv_head_args* args, pwv_stream_t stream);
  * WaveNet.__call__ (modules.py:138-165) without a host round trip per layer.
  *   buf0[g] holds the causal layer's output on entry; buf0/buf1 ping-pong through the layers;
  *   out[g] receives the net output [N,T,Q].
+ * With PWV_PREC_F16X3, no skip accumulation and no per-sample condition the head runs inside the last layer's
+ * launch (pwv_layer_args.head_packed) unless `separate_head` is set.
  * streams[0] only (streams[1] == NULL): every layer is one launch covering all G nets.
  * Two streams and G == 2: net g's chain runs on streams[g] with `max_workgroups` workgroups per
  * launch (0 = half of the CUs), launches interleaved -- the two independent chains then hide each
@@ -274,6 +282,7 @@ typedef struct pwv_stack_args {
      * ping-pong partner of buf1 and need not be initialised */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];
+    int separate_head;                            /* 1: never fuse the head into the last layer's launch */
 } pwv_stack_args;
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);

@@ -56,6 +56,9 @@ class LayerArgs(Structure):
         ('max_workgroups', c_int),
         ('x_first', c_void_p),
         ('causal_filter', c_void_p * PWV_MAX_NETS),
+        ('head_packed', c_void_p * PWV_MAX_NETS),
+        ('head_out', c_void_p * PWV_MAX_NETS),
+        ('head_q', c_int),
     ]
 
 
@@ -97,6 +100,7 @@ class StackArgs(Structure):
         ('ev_end', c_void_p * PWV_MAX_NETS),
         ('x_first', c_void_p),
         ('causal_filter', c_void_p * PWV_MAX_NETS),
+        ('separate_head', c_int),
     ]
 
 

@@ -593,8 +593,12 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     LayerParams lp{};
     bool any_skip = false;
     for (int g = 0; g < a->G; ++g) {
-        PWV_CHECK_ARG((a->x_in[g] || a->x_first) && a->x_out[g] && a->packed[g] && a->proj[g],
+        PWV_CHECK_ARG((a->x_in[g] || a->x_first) && (a->x_out[g] || a->head_packed[g]) && a->packed[g] && a->proj[g],
                       "pwv_wavenet_layer_f32: NULL buffer for net %d", g);
+        PWV_CHECK_ARG(!a->head_packed[0] == !a->head_packed[g] && (!a->head_packed[g] || a->head_out[g]),
+                      "pwv_wavenet_layer_f32: head_packed / head_out must be set for all nets or none");
+        lp.packed_head[g] = a->head_packed[g];
+        lp.head_out[g] = a->head_out[g];
         PWV_CHECK_ARG(!a->x_first || a->causal_filter[g], "pwv_wavenet_layer_f32: x_first needs causal_filter for net %d", g);
         lp.cfilt[g] = a->causal_filter[g];
         PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_layer_f32: in-place layers are not supported (x[t-d] halo)");
@@ -608,6 +612,9 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     for (int g = 0; g < a->G; ++g)
         PWV_CHECK_ARG(!any_skip || a->skip[g], "pwv_wavenet_layer_f32: skip must be set for all nets or none");
     PWV_CHECK_ARG(!a->x_first || a->precision == PWV_PREC_F16X3, "pwv_wavenet_layer_f32: x_first is implemented for PWV_PREC_F16X3 only");
+    PWV_CHECK_ARG(!a->head_packed[0] || (a->precision == PWV_PREC_F16X3 && a->out_mode == PWV_OUT_GATED && a->head_q >= 1 && a->head_q <= kMaxQ),
+                  "pwv_wavenet_layer_f32: a fused head needs PWV_PREC_F16X3, out_mode PWV_OUT_GATED and head_q in [1,%d]", kMaxQ);
+    lp.head_q = a->head_q;
     lp.x_first = a->x_first;
     lp.cond = a->cond;
     lp.proj_row_stride = a->proj_row_stride;
@@ -709,6 +716,8 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
         wgs = cus / 2 > 0 ? cus / 2 : 1;
     }
     const bool use_skip = a->skip[0] != nullptr;
+    // split-fp16 path, plain last layer: the head runs inside the last layer's launch (pwv_layer_args.head_packed)
+    const bool fuse_head = !a->separate_head && a->precision == PWV_PREC_F16X3 && !use_skip && !a->cond && a->n_layers >= 2;
     int cur = 0;
     for (int j = 0; j < a->n_layers; ++j) {
         const bool last = j == a->n_layers - 1;
@@ -736,6 +745,14 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
             la.out_mode = last ? PWV_OUT_GATED : PWV_OUT_RESIDUAL;
             la.precision = a->precision;
             la.max_workgroups = wgs;
+            if (last && fuse_head) {
+                for (int i = 0; i < per_group; ++i) {
+                    const int g = two ? grp : i;
+                    la.head_packed[i] = a->packed_head[g];
+                    la.head_out[i] = a->out[g];
+                }
+                la.head_q = a->Q;
+            }
             if (j == 0 && a->x_first) {
                 la.x_first = a->x_first;
                 for (int i = 0; i < per_group; ++i) la.causal_filter[i] = a->causal_filter[two ? grp : i];
@@ -747,7 +764,7 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
         }
         cur ^= 1;
     }
-    for (int grp = 0; grp < groups; ++grp) {
+    for (int grp = 0; grp < groups && !fuse_head; ++grp) {
         pwv_head_args ha{};
         ha.G = per_group;
         for (int i = 0; i < per_group; ++i) {

@@ -49,6 +49,9 @@ struct LayerParams {
     long long* trace;   // debug builds only (-DPWV_TRACE): per-wave phase timestamps
     const float* x_first;                   // layer 0 without a materialised causal layer: the scalar input [rows] ...
     const float* cfilt[PWV_MAX_NETS];       // ... and each net's causal filter [2,1,64] (split-fp16 kernel only)
+    const float* packed_head[PWV_MAX_NETS]; // last layer with the head fused behind it (split-fp16 kernel only)
+    float* head_out[PWV_MAX_NETS];
+    int head_q;
 };
 
 // exact n / d for n < 2^31 (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l) / d), shift = l - 1
@@ -110,15 +113,20 @@ struct HeadParams {
 constexpr float kFScale = -2.8853900817779268f;
 constexpr float kGScale = -1.4426950408889634f;
 __device__ __forceinline__ float gate_act(float fs, float gs) {
+#pragma clang fp contract(off)
     // upper clamp as ONE v_med3_f32 each (fminf would get a canonicalising v_max in front of it).  It must be an
     // instruction the compiler knows: fs / gs are MFMA results, and the hazard recogniser does not insert the
     // MFMA-write -> VALU-read wait states in front of inline asm (an asm v_min here read a stale accumulator
     // register whenever the scheduler placed it right behind the last MFMA).
     fs = __builtin_amdgcn_fmed3f(fs, -3.0e38f, 57.7f);
     gs = __builtin_amdgcn_fmed3f(gs, -3.0e38f, 57.7f);
+    // (1 + e1)(1 + e2) = t + e1 t with t = 1 + e2, written as ONE explicit fma and with contraction off: every
+    // instantiation of every kernel then rounds the gate identically (the fused-head / fused-first-layer variants are
+    // bit-identical to the separate launches, tests/test_gpu_parity.py) instead of leaving the choice to -ffp-contract
     const float e1 = __builtin_amdgcn_exp2f(fs);
     const float e2 = __builtin_amdgcn_exp2f(gs);
-    return (1.f - e1) * __builtin_amdgcn_rcpf((1.f + e1) * (1.f + e2));
+    const float t = 1.f + e2;
+    return (1.f - e1) * __builtin_amdgcn_rcpf(__builtin_fmaf(e1, t, t));
 }
 
 // One layer's / head's packed weights -> LDS (packed order == LDS order).  All loads of a thread are

@@ -97,12 +97,22 @@ __device__ __forceinline__ void first_frags(const f16x8* A, int lane, f16x8 (&h)
 // front kernel and reading them back twice (x[t], x[t-d]), the lane rebuilds its 32 channels of both rows from four
 // scalars with the same two fp32 operations per channel the front kernel uses (bit-identical): 4 B instead of 768 B of
 // traffic per sample for this layer, and no front launch.
-template <bool SKIP, bool COND, bool GATED, bool FIRST = false>
+//
+// HEAD: the LAST layer with the post-processing head (modules.py:145-165) fused behind it.  The gated output o never
+// leaves the registers it was accumulated in -- it is the B operand of the skip GEMM -- so the [rows, 64] round trip
+// through HBM between the last layer and the head (512 B per sample and net) and the head launch disappear.  LDS holds
+// exactly the three weight matrices (filter|gate 64 KB + skip 32 KB + postprocess1 64 KB = all 160 KB of the CU): the
+// small vectors (skip / postprocess1 biases, postprocess2) are read from global memory per unit like P, and units are
+// handed out statically (no room for a counter).
+template <bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
 __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
+    static_assert(!HEAD || (GATED && !SKIP && !COND && !FIRST), "HEAD: plain last layer only");
     constexpr int WAVES = 8;
-    constexpr int kLds = layer_floats(SKIP, COND);
+    constexpr int kLds = HEAD ? kA1Size + kASSize + kHA1Size : layer_floats(SKIP, COND);
     constexpr int kCF = kLds + 4;           // FIRST: the causal filter [2][64] behind the unit counter
-    __shared__ __attribute__((aligned(16))) float lds[kLds + 4 + (FIRST ? 128 : 0)];
+    constexpr int kHS = kA1Size;            // HEAD: skip weights, then postprocess1
+    constexpr int kH1 = kA1Size + kASSize;
+    __shared__ __attribute__((aligned(16))) float lds[kLds + (HEAD ? 0 : 4) + (FIRST ? 128 : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     const int net = blockIdx.x % p.G;
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
-    int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
+    int* unit_counter = reinterpret_cast<int*>(&lds[HEAD ? 0 : kLds]);      // unused with HEAD
 #ifdef PWV_TRACE
     if (p.trace && tid == 0) {
         p.trace[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -120,7 +130,9 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #endif
     // the first WAVES units are handed out statically (wave w takes unit w) so their rows can be
     // requested before the weights are staged; the counter then starts at WAVES
-    if (tid == 0) *unit_counter = WAVES;
+    if constexpr (!HEAD) {
+        if (tid == 0) *unit_counter = WAVES;
+    }
 
     constexpr int kAS = kLayerBase;
     constexpr int kBS = kAS + kASSize;
@@ -175,13 +187,19 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     if constexpr (FIRST) {
         if (tid < 128) lds[kCF + tid] = p.cfilt[net][tid];
     }
-    fill_lds_dma<kLds / 4, WAVES>(lds, p.packed[net], wave, lane);
+    if constexpr (HEAD) {
+        fill_lds_dma<kA1Size / 4, WAVES>(lds, p.packed[net] + kA1, wave, lane);
+        fill_lds_dma<kASSize / 4, WAVES>(lds + kHS, p.packed_head[net] + kHAS, wave, lane);
+        fill_lds_dma<kHA1Size / 4, WAVES>(lds + kH1, p.packed_head[net] + kHA1, wave, lane);
+    } else {
+        fill_lds_dma<kLds / 4, WAVES>(lds, p.packed[net], wave, lane);
+    }
     __syncthreads();
 #ifdef PWV_TRACE
     if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
 #endif
     while (unit < u_end) {
-        const int next = grab();
+        const int next = HEAD ? unit + WAVES : grab();
         ++tr_unit;
         PWV_STAMP(0);
         int row, rc, n, t;
@@ -307,7 +325,72 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 
         PWV_STAMP(5);
         float* orow = p.x_out[net] + tile_off(row, h, 64);
-        if constexpr (GATED) {
+        if constexpr (GATED && HEAD) {
+            // ---- fused head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2 -------------------
+            const float* hb = p.packed_head[net];
+            const f16x8* HS = reinterpret_cast<const f16x8*>(&lds[kHS]);
+            const f16x8* H1 = reinterpret_cast<const f16x8*>(&lds[kH1]);
+            f32x16 accs[4];      // starts at the skip bias (requested now, lands while pair 1 is gated)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHBS + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+            split8<16>(o, oh[2], ol[2]);
+            split8<24>(o, oh[3], ol[3]);
+            first_frags<4, 4, 0, 1, 4>(HS, lane, ah, al);
+            gemm16<4, 4, 0, 1, 4>(HS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; },
+                                  [&](int s) -> f16x8 { return ol[s]; }, no_extra,
+                                  [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 4, 0, 1, 4>(H1, lane, nh, nl); });
+            f32x16 acc1[4];      // starts at the postprocess1 bias
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHB1 + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = v[e];
+                }
+            f16x8 sh[8], sl[8];
+            {
+                float r[64];
+#pragma unroll
+                for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
+                split8<0>(r, sh[0], sl[0]);
+                split8<8>(r, sh[1], sl[1]);
+                split8<16>(r, sh[2], sl[2]);
+                split8<24>(r, sh[3], sl[3]);
+                split8<32>(r, sh[4], sl[4]);
+                split8<40>(r, sh[5], sl[5]);
+                split8<48>(r, sh[6], sl[6]);
+                split8<56>(r, sh[7], sl[7]);
+            }
+            gemm16<8, 4, 0, 1, 4>(H1, lane, acc1, ah, al, [&](int s) -> f16x8 { return sh[s]; },
+                                  [&](int s) -> f16x8 { return sl[s]; }, no_extra, [](f16x8(&)[4], f16x8(&)[4]) {});
+            load_x(next, rxb, rxc);      // the next unit's rows: in flight under the postprocess2 dot
+            const int Q = p.head_q;
+            for (int q = 0; q < Q; ++q) {
+                float part = 0.f;
+                const float* w2 = hb + kHW2 + (h * Q + q) * 64;
+#pragma unroll
+                for (int i4 = 0; i4 < 16; ++i4) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + 4 * i4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * i4 + e;
+                        part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[e], part);
+                    }
+                }
+                part += __shfl_xor(part, 32);
+                part += hb[kHW2 + 2 * Q * 64 + q];
+                if (valid && h == 0) p.head_out[net][(size_t)row * Q + q] = part;
+            }
+        } else if constexpr (GATED) {
             load_x(next, rxb, rxc);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -682,9 +765,9 @@ __global__ void pack_head_f16_kernel(const float* skip, const float* skip_bias, 
     if (base * 4 < total_floats) o32[base] = v;
 }
 
-template <bool SKIP, bool COND, bool GATED, bool FIRST = false>
+template <bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
 static int launch16(const LayerParams& lp, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED, FIRST>), dim3(grid), dim3(512), 0, s, lp);
+    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED, FIRST, HEAD>), dim3(grid), dim3(512), 0, s, lp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 layer kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
@@ -692,6 +775,11 @@ static int launch16(const LayerParams& lp, int grid, hipStream_t s) {
 
 int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, int per_net, hipStream_t s) {
     const int grid = per_net * lp.G;
+    if (lp.packed_head[0]) {
+        if (skip || cond || !gated || lp.x_first)
+            return set_error(PWV_EINVAL, "fused head: plain last layer only (no skip accumulation, no per-sample condition, not layer 0)");
+        return launch16<false, false, true, false, true>(lp, grid, s);
+    }
     if (lp.x_first) {
         if (skip) return set_error(PWV_EINVAL, "x_first (layer 0 without a materialised causal layer) does not support skip accumulation");
         if (cond) return gated ? launch16<false, true, true, true>(lp, grid, s) : launch16<false, true, false, true>(lp, grid, s);

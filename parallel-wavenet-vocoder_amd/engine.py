@@ -47,6 +47,8 @@ EVENT_LOG = None
 TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
 # PWV_FUSE_FIRST=0: materialise the causal layer with the front kernel even where layer 0 could rebuild it (A/B knob)
 FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
+# PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
+FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
 _side_streams = {}
 
 
@@ -377,6 +379,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     sa.cond_hop, sa.cond_offset, sa.cond_frames = (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0)
     sa.precision = prec
     sa.max_workgroups = max_workgroups
+    sa.separate_head = 0 if FUSE_HEAD else 1
     if first_fused:
         sa.x_first = _ptr(x)
         for g in range(G):

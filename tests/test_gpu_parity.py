@@ -320,7 +320,7 @@ def test_vocoder_random_configurations(gpu, seed):
 
 
 @pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
-def test_layer0_rebuilding_the_causal_layer_is_bit_identical(gpu, method, monkeypatch):
+def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, monkeypatch):
     """Split-fp16 path: layer 0 rebuilds h[t] = x[t-1] w0 + x[t] w1 from the scalar input (pwv_layer_args.x_first)
     with the front kernel's own two fp32 operations per channel -- switching the front kernel back on must not change
     a single bit (ragged length, several utterances, dilation of layer 0 > 1 in the second flow, a one-layer net)."""
@@ -333,4 +333,8 @@ def test_layer0_rebuilding_the_causal_layer_is_bit_identical(gpu, method, monkey
     monkeypatch.setattr(engine, 'FUSE_FIRST', False)
     b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
     assert np.array_equal(a, b)
+    # ... and the same for the head fused behind the last layer (the gated output stays in registers)
+    monkeypatch.setattr(engine, 'FUSE_HEAD', False)
+    c = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+    assert np.array_equal(a, c)
     assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
