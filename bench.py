@@ -298,13 +298,13 @@ def main():
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
         # MI355X_MICROARCH.md prescribes) are collected offline and committed under profiles/; quoted here only
         # when they were taken on this exact workload and kernel
-        tpath = os.path.join(ROOT, 'profiles', 'r01_d_hbm_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'r01_e_hbm_traffic.json')
         if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             # the PMC passes count bytes per launch of one net; a G = 2 launch (PWV_TWO_STREAMS=0) moves twice that
             common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
-            common['traffic_source'] = 'profiles/r01_d_hbm_traffic.json'
+            common['traffic_source'] = 'profiles/r01_e_hbm_traffic.json'
         if args.precision == 'f32':
             # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
             result['roofline'] = dict(kernel='layer_f32_kernel<8,0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
