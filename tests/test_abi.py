@@ -87,3 +87,13 @@ def test_header_is_plain_c():
         sizes = [int(x) for x in re.findall(r'\d+', subprocess.check_output([exe]).decode())]
     from pwv_amd import _lib
     assert sizes == [ctypes.sizeof(_lib.LayerArgs), ctypes.sizeof(_lib.HeadArgs), ctypes.sizeof(_lib.StackArgs)]
+
+
+def test_plain_c_client_builds(tmp_path):
+    """examples/c_abi_smoke.c: the boundary is usable from C99 with nothing but the header, the library and the HIP
+    runtime (it is RUN on the GPU by tests/test_gpu_parity.py::test_plain_c_client_runs)."""
+    from pwv_amd import _lib
+    from tests.util import build_c_abi_smoke
+    _lib.build_library()
+    res = build_c_abi_smoke(str(tmp_path / 'c_abi_smoke'))
+    assert res.returncode == 0, res.stdout

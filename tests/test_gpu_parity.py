@@ -338,3 +338,15 @@ def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, monkeyp
     c = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
     assert np.array_equal(a, c)
     assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
+
+
+def test_plain_c_client_runs(gpu, tmp_path):
+    """The C99 client (examples/c_abi_smoke.c) drives pwv_causal_conv_f32 and the tile32 converters with raw
+    hipMalloc'd pointers and checks them against loops written in C."""
+    import subprocess
+    from tests.util import build_c_abi_smoke
+    exe = str(tmp_path / 'c_abi_smoke')
+    res = build_c_abi_smoke(exe)
+    assert res.returncode == 0, res.stdout
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout

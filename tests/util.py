@@ -79,3 +79,16 @@ def f16_storage_model(weights, cfg):
         else:
             out[name] = v
     return out, r16
+
+
+def build_c_abi_smoke(out_path):
+    """Compile examples/c_abi_smoke.c (a plain C99 client of the C ABI: raw hipMalloc pointers, no Python / torch)
+    with gcc against the in-tree library.  Returns the command's CompletedProcess."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'parallel-wavenet-vocoder_amd')
+    cmd = ['gcc', '-std=c99', '-Wall', '-D__HIP_PLATFORM_AMD__', os.path.join(root, 'examples', 'c_abi_smoke.c'),
+           '-I' + os.path.join(root, 'include'), '-I/opt/rocm/include', '-L' + lib_dir, '-lpwv_hip', '-L/opt/rocm/lib',
+           '-lamdhip64', '-lm', '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib', '-o', out_path]
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
