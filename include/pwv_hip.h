@@ -99,6 +99,21 @@ int pwv_crop_time_f32(const float* in, float* out, int N, int T_in, int C, int T
 int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Range guard of the split-fp16 arithmetic (PWV_PREC_F16X3).  The reference computes in fp32 (models.py:81-82);
+ * the split-fp16 kernels convert GEMM operands to fp16 hi/lo pairs, which keeps fp32's ~22-bit products but has
+ * fp16's EXPONENT range: an operand beyond 65504 would become inf where fp32 is fine.  The host bounds every GEMM
+ * operand from the weights (pack time) and from two run-time maxima -- the flow input and the mel input -- which
+ * the kernels check against the limits the host derived:
+ *   pwv_range_flag(&p)      process-wide sticky int32 in pinned, device-visible host memory (0 = in range);
+ *                           the host reads it after any synchronisation, no device -> host copy needed.
+ *   pwv_range_check_f32     sets *flag = 1 when any x[i] is non-finite or |x[i]| > limit.
+ * A raised flag means: the result of that forward is not trustworthy in PWV_PREC_F16X3 -- rerun it in
+ * PWV_PREC_F32 (the Python host raises PwvRangeError / reruns).
+ * ------------------------------------------------------------------------------------- */
+int pwv_range_flag(int** flag);
+int pwv_range_check_f32(const float* x, int64_t n, float limit, int* flag, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * "tile32": the layout of every [rows = N*T, C] ACTIVATION buffer the fused kernels below read or
  * write (residual stream C = 64, skip sums C = 128, per-sample condition C = 80).  Rows are stored
  * in blocks of 32; block u holds rows 32u..32u+31 as [C/4 channel quads][32 rows][4 floats]:
@@ -206,6 +221,10 @@ typedef struct pwv_layer_args {
     const float* head_packed[PWV_MAX_NETS];     /* pwv_pack_head_f32 output */
     float* head_out[PWV_MAX_NETS];
     int head_q;
+    /* PWV_PREC_F16X3 range guard (see pwv_range_check_f32): with x_first set and range_flag != NULL, layer 0 sets
+     * *range_flag = 1 when a flow-input sample is non-finite or |x| > x_limit. */
+    float x_limit;
+    int* range_flag;
 } pwv_layer_args;
 
 int pwv_wavenet_layer_f32(const pwv_layer_args* args, pwv_stream_t stream);
@@ -283,6 +302,8 @@ typedef struct pwv_stack_args {
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];
     int separate_head;                            /* 1: never fuse the head into the last layer's launch */
+    float x_limit;                                /* forwarded to layer 0 (pwv_layer_args.x_limit / range_flag) */
+    int* range_flag;
 } pwv_stack_args;
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);

@@ -29,12 +29,17 @@ EXPORTED_SYMBOLS = (
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
-    'pwv_linear_split_f32', 'pwv_cond_split_f16',
+    'pwv_linear_split_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_range_check_f32',
 )
 
 
 class PwvError(RuntimeError):
     pass
+
+
+class PwvRangeError(PwvError):
+    """A split-fp16 ('f16x3') forward met an operand beyond fp16's exponent range (include/pwv_hip.h, range guard):
+    its result is not trustworthy; rerun with precision='f32'."""
 
 
 class LayerArgs(Structure):
@@ -59,6 +64,8 @@ class LayerArgs(Structure):
         ('head_packed', c_void_p * PWV_MAX_NETS),
         ('head_out', c_void_p * PWV_MAX_NETS),
         ('head_q', c_int),
+        ('x_limit', ctypes.c_float),
+        ('range_flag', c_void_p),
     ]
 
 
@@ -101,6 +108,8 @@ class StackArgs(Structure):
         ('x_first', c_void_p),
         ('causal_filter', c_void_p * PWV_MAX_NETS),
         ('separate_head', c_int),
+        ('x_limit', ctypes.c_float),
+        ('range_flag', c_void_p),
     ]
 
 
@@ -158,6 +167,8 @@ def _declare(lib):
     lib.pwv_pack_head_f32.argtypes = [f32p] * 6 + [c_int, c_int, f32p, c_void_p]
     lib.pwv_wavenet_head_f32.argtypes = [POINTER(HeadArgs), c_void_p]
     lib.pwv_wavenet_stack_f32.argtypes = [POINTER(StackArgs), POINTER(c_void_p)]
+    lib.pwv_range_flag.argtypes = [POINTER(c_void_p)]
+    lib.pwv_range_check_f32.argtypes = [f32p, c_int64, ctypes.c_float, c_void_p, c_void_p]
     for name in EXPORTED_SYMBOLS:      # fails loudly (AttributeError) if a symbol is missing
         getattr(lib, name)
     return lib

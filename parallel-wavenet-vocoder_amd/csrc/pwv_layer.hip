@@ -616,6 +616,8 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
                   "pwv_wavenet_layer_f32: a fused head needs PWV_PREC_F16X3, out_mode PWV_OUT_GATED and head_q in [1,%d]", kMaxQ);
     lp.head_q = a->head_q;
     lp.x_first = a->x_first;
+    lp.x_limit = a->x_limit;
+    lp.range_flag = a->x_first ? a->range_flag : nullptr;
     lp.cond = a->cond;
     lp.proj_row_stride = a->proj_row_stride;
     lp.G = a->G;
@@ -755,6 +757,8 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
             }
             if (j == 0 && a->x_first) {
                 la.x_first = a->x_first;
+                la.x_limit = a->x_limit;
+                la.range_flag = a->range_flag;
                 for (int i = 0; i < per_group; ++i) la.causal_filter[i] = a->causal_filter[two ? grp : i];
             }
             if (j == 0 && a->ev_begin[grp]) PWV_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin[grp], (hipStream_t)streams[grp]));

@@ -52,6 +52,8 @@ struct LayerParams {
     const float* packed_head[PWV_MAX_NETS]; // last layer with the head fused behind it (split-fp16 kernel only)
     float* head_out[PWV_MAX_NETS];
     int head_q;
+    float x_limit;                          // range guard of the split-fp16 arithmetic (x_first path): |x| <= x_limit ...
+    int* range_flag;                        // ... else *range_flag = 1 (pinned host memory); NULL = no check
 };
 
 // exact n / d for n < 2^31 (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l) / d), shift = l - 1

@@ -245,6 +245,8 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             // as iaf_front_kernel: round(x[t-1] w0), then fma(x[t], w1, .)
             const float x0 = rxc[0], x1v = rxc[1], xd0 = rxb[0], xd1 = rxb[1];
             const bool has_prev = t >= p.dilation;
+            // range guard (include/pwv_hip.h): every row is some lane's x[t]; NaN fails the comparison too
+            if (p.range_flag && !(fabsf(x0) <= p.x_limit)) __hip_atomic_store(p.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCF + 8 * g + 4 * h]);

@@ -384,6 +384,12 @@ __global__ void tile32_kernel(const float* __restrict__ in, float* __restrict__ 
     *reinterpret_cast<f32x4*>(out + (TO_TILE ? til : lin)) = *reinterpret_cast<const f32x4*>(in + (TO_TILE ? lin : til));
 }
 
+// range guard of the split-fp16 arithmetic (include/pwv_hip.h): one pass over a small tensor (flow input, mel)
+__global__ void range_check_kernel(const float* __restrict__ x, long long n, float limit, int* flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(fabsf(x[i]) <= limit)) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static inline unsigned blocks_for(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
 
 }  // namespace pwv
@@ -393,7 +399,26 @@ using namespace pwv;
 extern "C" {
 
 const char* pwv_last_error(void) { return error_buffer(); }
-int pwv_version(void) { return 100; }
+int pwv_version(void) { return 200; }
+
+int pwv_range_flag(int** flag) {
+    static int* g_flag = nullptr;      // process lifetime; pinned + mapped: the same pointer is valid on host and device
+    PWV_CHECK_ARG(flag, "pwv_range_flag: NULL argument");
+    if (!g_flag) {
+        PWV_CHECK_HIP(hipHostMalloc((void**)&g_flag, sizeof(int), hipHostMallocMapped | hipHostMallocPortable));
+        *g_flag = 0;
+    }
+    *flag = g_flag;
+    return PWV_OK;
+}
+
+int pwv_range_check_f32(const float* x, int64_t n, float limit, int* flag, pwv_stream_t stream) {
+    PWV_CHECK_ARG(x && flag && n >= 0, "pwv_range_check_f32: bad arguments");
+    if (n == 0) return PWV_OK;
+    hipLaunchKernelGGL(range_check_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, limit, flag);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
 int pwv_device_cus(void) {
     const int c = device_cus();
     return c > 0 ? c : set_error(PWV_EHIP, "no HIP device available");

@@ -59,6 +59,45 @@ def _net_streams(device):
     return _side_streams[key]
 
 
+# ---- range guard of the split-fp16 arithmetic (include/pwv_hip.h, "Range guard") -------------------------------
+F16_LIMIT = 65000.0          # fp16 max is 65504; stay below the value that rounds up to inf
+_range_flag_addr = None
+_range_warned = set()
+
+
+def range_flag_ptr() -> int:
+    """Address of the library's sticky overflow flag (pinned host memory, also valid on the device)."""
+    global _range_flag_addr
+    if _range_flag_addr is None:
+        p = c_void_p()
+        check(_lib.lib().pwv_range_flag(ctypes.byref(p)), 'pwv_range_flag')
+        _range_flag_addr = p.value
+    return _range_flag_addr
+
+
+def range_flag_raised() -> bool:
+    """True once a split-fp16 forward that has COMPLETED met an out-of-range operand (no synchronisation here)."""
+    return _range_flag_addr is not None and ctypes.c_int.from_address(_range_flag_addr).value != 0
+
+
+def clear_range_flag() -> None:
+    if _range_flag_addr is not None:
+        ctypes.c_int.from_address(_range_flag_addr).value = 0
+
+
+def raise_if_range_flag(where: str = '') -> None:
+    if range_flag_raised():
+        clear_range_flag()
+        raise _lib.PwvRangeError("a split-fp16 ('f16x3') forward%s met an activation or input beyond fp16's exponent range "
+                                 "(or a non-finite one): its result is not trustworthy -- rerun with precision='f32'"
+                                 % (' (%s)' % where if where else ''))
+
+
+def range_check_op(x: torch.Tensor, limit: float) -> None:
+    """Enqueue the check |x| <= limit (and finite) on the current stream; a violation raises the sticky flag."""
+    check(_lib.lib().pwv_range_check_f32(_ptr(x), x.numel(), float(limit), range_flag_ptr(), _stream()), 'pwv_range_check_f32')
+
+
 def _stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -208,6 +247,35 @@ class NetPlan:
                                     net.out_channels, precision, _ptr(self.packed_head), s), 'pwv_pack_head_f32')
         self.causal_filter = net.causal_filter()
         self.n_layers = L
+        self.f16x3_ok, self.x_limit = True, 3.0e38
+        if precision == _lib.PREC_F16X3:
+            self._range_analysis(net, L, use_skip, cond_mode)
+
+    def _range_analysis(self, net, L, use_skip, cond_mode):
+        """Bound every operand the split-fp16 kernels convert to fp16 (weights after the exp2 scale folding; the residual
+        stream |x_j| <= |h| + sum_i (||dense_i||_1 + |dense_bias_i|) because |tanh * sigmoid| < 1; relu(skip) feeding the
+        head) from the weights alone.  What remains is a limit on the flow input, checked on the device at run time."""
+        kf, kg = 2.8853900817779268, 1.4426950408889634
+        wmax, c_res, skip_terms = [], [], []
+        for j in range(L):
+            v = net.layer_variables(j, with_cond=cond_mode != 'none')
+            wmax += [v['filter'].abs().max() * kf, v['gate'].abs().max() * kg, v['dense'].abs().max(), v['skip'].abs().max()]
+            if cond_mode != 'none':
+                wmax += [v['gc_filter'].abs().max() * kf, v['gc_gate'].abs().max() * kg]
+            if j < L - 1:
+                c = v['dense'][0].abs().sum(dim=0).max()
+                c_res.append(c + v['dense_bias'].abs().max() if 'dense_bias' in v else c)
+            if use_skip or j == L - 1:
+                c = v['skip'][0].abs().sum(dim=0).max()
+                skip_terms.append(c + v['skip_bias'].abs().max() if 'skip_bias' in v else c)
+        hv = net.head_variables()
+        wmax.append(hv['postprocess1'].abs().max())
+        zero = torch.zeros((), device=self.causal_filter.device)
+        stats = torch.stack([torch.stack(wmax).max(), torch.stack(c_res).sum() if c_res else zero, torch.stack(skip_terms).sum(),
+                             self.causal_filter.abs().sum(dim=(0, 1)).max()]).cpu().tolist()
+        w_max, res_bound, skip_bound, c_causal = stats
+        self.f16x3_ok = w_max < F16_LIMIT and skip_bound < F16_LIMIT and res_bound < F16_LIMIT
+        self.x_limit = (F16_LIMIT - res_bound) / c_causal if c_causal > 0 else 3.0e38
 
 
 _plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
@@ -215,7 +283,11 @@ _cond_cache = None      # (weakref(condition tensor), its version, precision, co
 
 
 def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
-    key = (net.store.uid, net.full_scope, cond_mode, precision)
+    # the architecture is part of the key: the same store + scope can be re-used with another dilation list or with
+    # use_skip_connection toggled (no variable is created then, so the store version alone does not change)
+    key = (net.store.uid, net.full_scope, cond_mode, precision, tuple(int(d) for d in net.dilations),
+           bool(net.use_skip_connection), bool(net.use_biases), net.in_channels, net.out_channels,
+           net.condition_channels, net.filter_width, net.residual_channels, net.dilation_channels, net.skip_channels)
     hit = _plan_cache.get(key)
     if hit is not None and hit[0] == net.store.version:
         return hit[1]
@@ -278,7 +350,18 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     if half and (qin != 1 or net0.use_skip_connection):
         raise _lib.PwvError("precision 'f16' supports scalar-input nets without skip accumulation only")
     plans = [get_plan(net, mode, prec) for net in nets]
+    if prec == _lib.PREC_F16X3 and not all(p.f16x3_ok and p.x_limit > 0 for p in plans):
+        # some weight / bound leaves fp16's exponent range: this net runs in the exact fp32 arithmetic instead
+        key = tuple(net.full_scope for net in nets)
+        if key not in _range_warned:
+            _range_warned.add(key)
+            import warnings
+            warnings.warn("pwv: weights of %s exceed the range of the split-fp16 arithmetic; using precision 'f32' for it" % (key,))
+        return run_nets(nets, x, cond, precision='f32', max_workgroups=max_workgroups)
+    x_limit = min(p.x_limit for p in plans)
     L = plans[0].n_layers
+    for net, plan in zip(nets, plans):
+        assert plan.n_layers == len(net.dilations) and plan.with_skip == bool(net.use_skip_connection)
     rows = n * t
 
     def tile_buf(channels, dtype=torch.float32):
@@ -336,6 +419,8 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # so the [rows, 64] front buffer is neither written nor read
     first_fused = (FUSE_FIRST and prec == _lib.PREC_F16X3 and qin == 1 and net0.filter_width == 2 and R == 64
                    and not net0.use_skip_connection)
+    if prec == _lib.PREC_F16X3 and not first_fused:
+        range_check_op(x, x_limit)          # (layer 0 checks its scalar input itself when it rebuilds the causal layer)
     if first_fused:
         pass
     elif qin == 1:
@@ -382,6 +467,8 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     sa.separate_head = 0 if FUSE_HEAD else 1
     if first_fused:
         sa.x_first = _ptr(x)
+        sa.x_limit = x_limit
+        sa.range_flag = range_flag_ptr()
         for g in range(G):
             sa.causal_filter[g] = plans[g].causal_filter.data_ptr()
     streams = (c_void_p * 2)(side[0].cuda_stream if two else s.value, side[1].cuda_stream if two else None)

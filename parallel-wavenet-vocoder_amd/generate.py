@@ -23,6 +23,7 @@ import sys
 import numpy as np
 import torch
 
+from ._lib import PwvRangeError
 from .hparam import hparam as hp
 from .models import IAFVocoder
 from .variables import reset_default_store
@@ -94,7 +95,6 @@ def generate(case='default', ckpt=None, debug=False):
     ckpt = '{}/{}'.format(logdir, ckpt) if ckpt else (_latest_checkpoint(logdir) if os.path.isdir(logdir) else None)
     if ckpt:
         n = store.load_checkpoint(ckpt, use_ema=bool(hp.train.use_ema))
-        print('Successfully loaded checkpoint {} ({} variables)'.format(ckpt, n))
     else:
         print('No checkpoint found at {}.'.format(logdir))
 
@@ -103,6 +103,21 @@ def generate(case='default', ckpt=None, debug=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     pred = model(gt_wav, melspec, is_training=False)         # feed forward
+    try:
+        model.verify()
+    except PwvRangeError as e:
+        # the reference computes in fp32 (models.py:81-82): outside the range of the split-fp16 arithmetic, rerun in it
+        print('%s\nre-running the forward with exact fp32 arithmetic' % e)
+        model = IAFVocoder(batch_size=batch_size, length=length, store=store, precision='f32')
+        pred = model(gt_wav, melspec, is_training=False)
+    if ckpt:
+        # tf.train.Saver.restore fails on a variable the checkpoint lacks (generate.py:59-63); here variables are
+        # created lazily by the forward, so the coverage check comes after it
+        missing = store.not_restored()
+        if missing:
+            raise KeyError('checkpoint %s does not hold %d of the model\'s %d variables (they would be random-initialised): %s%s'
+                           % (ckpt, len(missing), len(store.vars), ', '.join(missing[:6]), ' ...' if len(missing) > 6 else ''))
+        print('Successfully loaded checkpoint {} ({} variables)'.format(ckpt, n))
     if debug:
         e1.record()
         torch.cuda.synchronize()
@@ -124,24 +139,26 @@ def generate(case='default', ckpt=None, debug=False):
 
 
 def _fire(fn, argv):
-    """Minimal python-fire work-alike: positionals, --name=value, --name value, --flag."""
+    """Minimal python-fire work-alike: positionals, --name=value, --name value, --flag (a bare flag may be followed by
+    another option: `generate c --debug --ckpt foo`)."""
     pos, kw = [], {}
-    it = iter(argv)
-    for a in it:
-        if a.startswith('--'):
-            k, eq, v = a[2:].partition('=')
-            if not eq:
-                nxt = next(it, None)
-                if nxt is None or nxt.startswith('--'):
-                    kw[k] = True
-                    if nxt is not None:
-                        k2, eq2, v2 = nxt[2:].partition('=')
-                        kw[k2] = v2 if eq2 else True
-                    continue
-                v = nxt
-            kw[k.replace('-', '_')] = {'True': True, 'False': False}.get(v, v)
-        else:
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        i += 1
+        if not a.startswith('--'):
             pos.append(a)
+            continue
+        k, eq, v = a[2:].partition('=')
+        k = k.replace('-', '_')
+        if not eq:
+            if i < len(argv) and not argv[i].startswith('--'):
+                v = argv[i]
+                i += 1
+            else:
+                kw[k] = True           # bare flag; the next token (if any) is an option of its own
+                continue
+        kw[k] = {'True': True, 'False': False}.get(v, v)
     return fn(*pos, **kw)
 
 

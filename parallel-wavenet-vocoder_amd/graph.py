@@ -37,7 +37,6 @@ class GraphedVocoder(object):
         n, length = int(model.batch_size), int(model.length)
         self.mel = torch.zeros((n, model.t_mel, int(hp.signal.n_mels)), dtype=torch.float32, device=self.device)
         self.z = torch.zeros((n, length, 1), dtype=torch.float32, device=self.device)
-        self.noise_calls = 0
         self._warmup = warmup
         self._capture()
 
@@ -65,9 +64,7 @@ class GraphedVocoder(object):
             raise ValueError('melspec must be %s (fixed at capture), got %s' % (tuple(self.mel.shape), tuple(melspec.shape)))
         self.mel.copy_(melspec, non_blocking=True)
         if z is None:
-            engine.logistic_noise_op(self.z.shape, self.device, seed=self.model.noise_seed if seed is None else seed,
-                                     offset=self.noise_calls * self.z.numel(), out=self.z)
-            self.noise_calls += 1
+            self.model.sample_noise(self.z.shape[0], self.device, out=self.z, seed=seed)
         else:
             if tuple(z.shape) != tuple(self.z.shape):
                 raise ValueError('z must be %s, got %s' % (tuple(self.z.shape), tuple(z.shape)))

@@ -27,7 +27,23 @@ class IAFVocoder(object):
         self.store = store
         self.precision = precision
         self.ema = None
-        self.noise_seed = 1
+        # Logistic noise (models.py:32-33 draws a fresh sample per sess.run): counter-based sampler, one seed per model
+        # object and a running offset so that every call -- eager or graph replay -- continues the same stream.  The
+        # default seed is drawn from the OS (PWV_NOISE_SEED pins it); ranks of a sharded job get different seeds that way.
+        self.noise_seed = None
+        self.noise_calls = 0
+
+    def sample_noise(self, n, device, out=None, seed=None):
+        """[n, length, 1] Logistic(0,1) noise (models.py:32-33); consecutive calls draw consecutive counter ranges."""
+        import os
+        if self.noise_seed is None:
+            env = os.environ.get('PWV_NOISE_SEED')
+            self.noise_seed = int(env) if env else int.from_bytes(os.urandom(7), 'little')
+        numel = n * self.length
+        z = engine.logistic_noise_op((n, self.length, 1), device, seed=self.noise_seed if seed is None else seed,
+                                     offset=self.noise_calls * numel, out=out)
+        self.noise_calls += 1
+        return z
 
     # -- network (models.py:23-78) -------------------------------------------------------------------
     def __call__(self, wav, melspec, is_training=False, name='iaf_vocoder', z=None):
@@ -35,6 +51,7 @@ class IAFVocoder(object):
         GPU.  ``z`` (optional, [N, length, 1]) replaces the logistic noise sampled at
         models.py:32-33 so results are reproducible against the oracle."""
         store = self.store or get_default_store()
+        engine.raise_if_range_flag('an earlier call')       # sticky flag of a forward that has completed since
         melspec = engine._require_cuda_f32(melspec, 'melspec')
         if melspec.dim() != 3 or melspec.shape[1] != self.t_mel or melspec.shape[2] != hp.signal.n_mels:
             raise ValueError('melspec must be [N, %d, %d], got %s' % (self.t_mel, hp.signal.n_mels, tuple(melspec.shape)))
@@ -50,7 +67,7 @@ class IAFVocoder(object):
                         condition = normalize(condition, is_training, hp.model.normalize_cond, store=store)
 
             if z is None:   # Logistic(0,1) noise, models.py:32-33
-                input = engine.logistic_noise_op((n, self.length, 1), melspec.device, seed=self.noise_seed)
+                input = self.sample_noise(n, melspec.device)
             else:
                 input = engine._require_cuda_f32(z, 'z')
                 if tuple(input.shape) != (n, self.length, 1):
@@ -84,6 +101,27 @@ class IAFVocoder(object):
                 input = normalize(input, is_training, hp.model.normalize, name='normalize{}'.format(i), store=store)
         return input
 
+    def verify(self):
+        """Wait for the enqueued forwards and raise PwvRangeError if one of them left the range of the split-fp16
+        arithmetic (the reference computes in fp32, models.py:81-82; see include/pwv_hip.h "Range guard")."""
+        import torch
+        torch.cuda.synchronize()
+        engine.raise_if_range_flag()
+
+    def _mel_limit(self, weights, store):
+        """Largest |mel| for which every operand of the conditioning GEMMs stays inside fp16's range: each stage is
+        relu(x @ w), so |out| <= |x|max * max column sum of |w|.  Cached per store version."""
+        import torch
+        key = (store.uid, store.version, len(weights))
+        if getattr(self, '_mel_limit_key', None) != key:
+            norms = torch.stack([w.abs().sum(dim=0).max() for w in weights]).cpu().tolist()
+            bound, worst = 1.0, 1.0
+            for nrm in norms:
+                bound *= nrm
+                worst = max(worst, bound)
+            self._mel_limit_key, self._mel_limit_val = key, engine.F16_LIMIT / worst
+        return self._mel_limit_val
+
     # -- condition upsampling (models.py:105-136) ----------------------------------------------------
     def _condition(self, melspec, is_training, strides, store):
         """The condition in the form the kernels want: a lazy RepeatedCondition for 'repeat'
@@ -101,10 +139,15 @@ class IAFVocoder(object):
             cond = melspec.reshape(n * t_mel, n_mels)
             length = t_mel
             input_channels = n_mels
+            wmats = []
             for i, stride in enumerate(strides):
-                w = get_variable('transposed_conv_{}_weights'.format(i), (1, stride, C, input_channels), store=store)
+                w = get_variable('transposed_conv_{}_weights'.format(i), (1, stride, C, input_channels if i == 0 else C), store=store)
                 # kernel width == stride: out[t*s + j, co] = sum_ci in[t, ci] * w[0, j, co, ci]  (a GEMM)
-                wmat = w[0].permute(2, 0, 1).reshape(input_channels, stride * C).contiguous()
+                wmats.append(w[0].permute(2, 0, 1).reshape(w.shape[3], stride * C).contiguous())
+            if (self.precision or engine.DEFAULT_PRECISION) == 'f16x3':
+                engine.range_check_op(melspec, self._mel_limit(wmats, store))
+            for i, stride in enumerate(strides):
+                wmat = wmats[i]
                 cond = engine.linear_op(cond, wmat, None, relu=True, precision=self.precision)   # models.py:118-120
                 input_channels = C
                 length *= stride
@@ -116,6 +159,8 @@ class IAFVocoder(object):
             return engine.crop_time_op(cond, length - hop, hop // 2)            # models.py:124
         elif method == 'repeat':
             w = get_variable('dense', [1, n_mels, C], store=store)
+            if (self.precision or engine.DEFAULT_PRECISION) == 'f16x3':
+                engine.range_check_op(melspec, self._mel_limit([w[0]], store))
             frames = engine.linear_op(melspec.reshape(n * t_mel, n_mels), w[0], None, relu=True,
                                       precision=self.precision)                              # models.py:128-130
             return RepeatedCondition(frames.reshape(n, t_mel, C), hop, hop // 2, self.length)      # models.py:131-133

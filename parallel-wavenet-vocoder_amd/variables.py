@@ -30,6 +30,7 @@ class VariableStore:
         self.seed = seed
         self.vars: Dict[str, torch.Tensor] = {}
         self.version = 0            # bumped on every change; packed-weight caches key on it
+        self.restored = set()       # names set from a checkpoint / dict (what tf.train.Saver.restore covered)
 
     # -- tf.get_variable -------------------------------------------------------------------
     def get_variable(self, name: str, shape: Sequence[int], initializer: Optional[str] = None) -> torch.Tensor:
@@ -77,6 +78,7 @@ class VariableStore:
                     raise KeyError(name)
                 continue
             self.assign(name.split(':')[0], weights[key])
+            self.restored.add(name.split(':')[0])
             loaded += 1
         return loaded
 
@@ -97,6 +99,10 @@ class VariableStore:
             keep = lambda n: not (n.endswith('/Adam') or n.endswith('/Adam_1'))
             return self.load_dict(read_tf_checkpoint(path, name_filter=keep), use_ema=use_ema)
         raise FileNotFoundError('no checkpoint at %s (.npz or TF V2 .index/.data)' % path)
+
+    def not_restored(self):
+        """Model variables that exist but were never set from a checkpoint (i.e. carry their random initialisation)."""
+        return sorted(k for k in self.vars if k not in self.restored)
 
     def save_npz(self, path: str) -> None:
         np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.vars.items()})

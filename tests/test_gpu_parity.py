@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import iaf_oracle as O
+from pwv_amd._lib import PwvRangeError
 from tests.util import TOL_F32, run_vocoder_hip, set_hparams, small_cfg
 
 pytestmark = pytest.mark.gpu
@@ -161,10 +162,54 @@ def test_large_magnitude_activations_f16x3(gpu, zscale, wscale):
     mel, z = O.synthetic_inputs(1, 480, cfg)
     z = z * zscale
     want = O.iaf_vocoder_forward(weights, mel, z, cfg)
-    e16 = np.abs(run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3') - want).max()
     e32 = np.abs(run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f32') - want).max()
     scale = max(1.0, np.abs(want).max())
+    try:
+        e16 = np.abs(run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3') - want).max()
+    except PwvRangeError:
+        return      # the (conservative) range guard refused the input: loud, and the f32 path above is the answer
     assert np.isfinite(e16) and e16 <= max(3 * e32, 2e-5 * scale) and e16 <= 2e-4 * scale, (e16, e32, scale)
+
+
+@pytest.mark.parametrize('zscale,wscale,melscale', [(1e4, 1, 1), (1, 64, 1), (1e4, 64, 1), (1, 1, 1e5), (float('nan'), 1, 1)])
+def test_f16x3_range_guard_never_returns_garbage(gpu, zscale, wscale, melscale):
+    """fp16 has 5 exponent bits: a GEMM operand beyond 65504 would turn into inf in the split-fp16 kernels where the
+    reference's fp32 (models.py:81-82) is fine.  Outside the range the path must EITHER still match the fp64 oracle as
+    well as the exact-fp32 path does (weights alone out of range: the plan falls back to 'f32') OR raise PwvRangeError
+    -- never hand back inf / garbage silently.  The f32 rerun is then the answer."""
+    import warnings
+    cfg = small_cfg()
+    weights = {k: (v * wscale if v.ndim > 1 else v) for k, v in O.init_weights(cfg, seed=6).items()}
+    mel, z = O.synthetic_inputs(1, 480, cfg)
+    z = (z * zscale).astype(np.float32)
+    mel = (mel * melscale).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if not np.isfinite(zscale):
+            with pytest.raises(PwvRangeError):
+                run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+            return
+        with np.errstate(all='ignore'):
+            want = O.iaf_vocoder_forward(weights, mel, z, cfg)
+        scale = max(1.0, np.abs(want).max())
+        y32 = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f32')
+        e32 = np.abs(y32 - want).max()
+        assert np.isfinite(y32).all() and e32 <= 1e-3 * scale, (e32, scale)
+        try:
+            y16 = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+        except PwvRangeError:
+            raised = True
+        else:
+            raised = False
+            e16 = np.abs(y16 - want).max()
+            assert np.isfinite(y16).all() and e16 <= max(3 * e32, 2e-5 * scale), (e16, e32, scale)
+        if melscale > 1:
+            assert raised            # |mel| * ||dense||_1 is beyond fp16 for sure
+        # the flag is sticky only until it has been reported: the next in-range forward is clean
+        mel1, z1 = O.synthetic_inputs(1, 480, cfg)
+        w1 = O.init_weights(cfg, seed=6)
+        got = run_vocoder_hip(cfg, w1, mel1, z1, gpu, precision='f16x3')
+        assert np.abs(got - O.iaf_vocoder_forward(w1, mel1, z1, cfg)).max() <= TOL_F32
 
 
 def test_plan_cache_is_per_store(gpu):

@@ -65,13 +65,69 @@ def test_generate_end_to_end_with_tf_checkpoint(gpu, tmp_path, monkeypatch):
     T.write_tf_checkpoint(str(logdir / 'model-100'), ck)
     (logdir / 'checkpoint').write_text('model_checkpoint_path: "model-100"\n')
     monkeypatch.setenv('PWV_LOGDIR', str(logdir))
-    monkeypatch.setattr('pwv_amd.engine.logistic_noise_op', lambda shape, device, seed, offset=0: torch.zeros(shape, device=device))
+    monkeypatch.setattr('pwv_amd.engine.logistic_noise_op', lambda shape, device, seed, offset=0, out=None: torch.zeros(shape, device=device))
     pred = generate('bench/c1')
     assert pred.shape == (1, 16000, 1)
     mel = (torch.rand((1, 201, 80), generator=torch.Generator().manual_seed(0)) * 2 - 1).numpy()
     want = O.iaf_vocoder_forward(ema, mel, np.zeros((1, 16000, 1), np.float32), cfg)
     assert np.abs(pred - want).max() <= TOL_F32
     assert os.path.exists(logdir / 'pred_0.wav') and os.path.exists(logdir / 'pred_wav.npy')
+    # a checkpoint that lacks a model variable must fail like tf.train.Saver.restore (generate.py:59-63), not
+    # silently run on random weights
+    short = {k: v for k, v in ck.items() if 'layer3/dense' not in k}
+    T.write_tf_checkpoint(str(logdir / 'model-200'), short)
+    (logdir / 'checkpoint').write_text('model_checkpoint_path: "model-200"\n')
+    with pytest.raises(KeyError, match='layer3/dense'):
+        generate('bench/c1')
+
+
+def test_sampled_noise_differs_between_calls_and_models(gpu):
+    """models.py:32-33 draws fresh Logistic noise per sess.run: consecutive forwards of one model, an eager and a
+    graph-replayed forward, and two model objects must not repeat the same noise."""
+    import torch
+    from pwv_amd.graph import GraphedVocoder
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    cfg = small_cfg()
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=2))
+    mel = torch.from_numpy(O.synthetic_inputs(1, 800, cfg)[0]).to(gpu)
+    m = IAFVocoder(batch_size=1, length=800, store=store)
+    a, b = m(None, mel), m(None, mel)
+    assert not torch.equal(a, b)
+    g = GraphedVocoder(m)
+    c = g(mel).clone()
+    d = g(mel).clone()
+    assert not torch.equal(c, d) and not torch.equal(c, a) and not torch.equal(c, b)
+    m2 = IAFVocoder(batch_size=1, length=800, store=store)
+    assert not torch.equal(m2(None, mel), a)
+    # a pinned seed reproduces the stream
+    m3, m4 = IAFVocoder(1, 800, store=store), IAFVocoder(1, 800, store=store)
+    m3.noise_seed = m4.noise_seed = 77
+    assert torch.equal(m3(None, mel), m4(None, mel))
+
+
+def test_plan_cache_distinguishes_architectures_in_one_scope(gpu):
+    """Two WaveNets built in the SAME store + scope with different structure (skip accumulation toggled, fewer
+    layers): no variable is created by the second one, so the packed-plan cache must key on the architecture."""
+    import torch
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    store = VariableStore(device=gpu, seed=3)
+    kw = dict(batch_size=1, filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
+              quantization_channels=1, use_biases=True, condition_channels=None, is_training=False, name='net', store=store)
+    x = torch.randn(1, 300, 1, device=gpu)
+    full = WaveNet(dilations=[1, 2, 4, 8], use_skip_connection=True, **kw)
+    y_skip = full(x)
+    w = {k: v.cpu().numpy() for k, v in store.vars.items()}
+    plain = WaveNet(dilations=[1, 2, 4, 8], use_skip_connection=False, **kw)
+    short = WaveNet(dilations=[1, 2], use_skip_connection=False, **kw)
+    y_plain, y_short = plain(x), short(x)
+    xn = x.cpu().numpy().astype(np.float64)
+    for y, dil, skip in ((y_skip, [1, 2, 4, 8], True), (y_plain, [1, 2, 4, 8], False), (y_short, [1, 2], False)):
+        want = O.wavenet_forward(w, 'net', xn, None, dil, True, skip)
+        assert np.abs(y.cpu().numpy() - want).max() <= TOL_F32
 
 
 def test_generate_sharded_over_rccl_world1(gpu):

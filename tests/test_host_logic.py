@@ -130,3 +130,21 @@ def test_time_shard_plan():
     assert len(shard_plan(160, 8, 6160, 80)) == 2                            # never more shards than frames
     with pytest.raises(ValueError):
         shard_plan(100, 2, 0, 80)
+
+
+def test_fire_style_cli_parsing():
+    """python-fire accepts `generate c --debug --ckpt foo` (a bare flag followed by a spaced option): ADVICE r1."""
+    from pwv_amd.generate import _fire
+    seen = {}
+
+    def fn(case='default', ckpt=None, debug=False):
+        seen.update(case=case, ckpt=ckpt, debug=debug)
+
+    _fire(fn, ['c', '--debug', '--ckpt', 'foo'])
+    assert seen == dict(case='c', ckpt='foo', debug=True)
+    _fire(fn, ['--ckpt=model-1', '--debug=False', 'x'])
+    assert seen == dict(case='x', ckpt='model-1', debug=False)
+    _fire(fn, ['y', '--debug'])
+    assert seen == dict(case='y', ckpt=None, debug=True)
+    _fire(fn, ['--some-flag'.replace('some-flag', 'debug'), '--ckpt', 'a-b'])
+    assert seen == dict(case='default', ckpt='a-b', debug=True)

@@ -196,3 +196,27 @@ def test_instance_norm_and_bn_identity_defaults():
     y = O.normalize(x, 'in', {}, 's')
     assert np.allclose(y.mean(axis=1), 0, atol=1e-12) and np.allclose(y.var(axis=1), 1, atol=1e-6)
     assert np.allclose(O.normalize(x, 'bn', {}, 's'), x / np.sqrt(1 + 1e-3))
+
+
+@pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
+def test_window_restatement_used_by_the_full_size_gpu_tests(method):
+    """tests/test_gpu_fullsize.py checks the END of a full-size run against the oracle run on a late window
+    [s, L): pin that window logic (mel frame slicing, halo discard) on the oracle itself."""
+    from pwv_amd.timeshard import chain_halo
+    cfg = O.ModelConfig(dilations=[[1, 2, 4, 8], [1, 2, 4, 8, 16]], n_iaf=2, cond_upsample_method=method)
+    hop = cfg.hop_length
+    halo = chain_halo(cfg.dilations, cfg.filter_width, cfg.n_iaf, hop)
+    assert halo == 80
+    w = O.init_weights(cfg, seed=5)
+    L, keep = 1600, 400
+    mel, z = O.synthetic_inputs(2, L, cfg)
+    full = O.iaf_vocoder_forward(w, mel, z, cfg)
+    s = L - keep - halo
+    win = O.iaf_vocoder_forward(w, mel[1:2, s // hop:], z[1:2, s:], cfg)
+    assert np.abs(full[1:2, L - keep:] - win[:, halo:]).max() <= 1e-12
+    K = 800
+    pre = O.iaf_vocoder_forward(w, mel[:, :K // hop + 1], z[:, :K], cfg)
+    assert np.abs(full[:, :K - hop // 2] - pre[:, :K - hop // 2]).max() <= 1e-12
+    # one hop less of halo than the receptive field needs is NOT enough (the check has teeth)
+    win2 = O.iaf_vocoder_forward(w, mel[1:2, (s + hop) // hop:], z[1:2, s + hop:], cfg)
+    assert np.abs(full[1:2, s + hop + 16:s + hop + 30] - win2[:, 16:30]).max() > 1e-9

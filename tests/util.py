@@ -46,7 +46,7 @@ def run_vocoder_hip(cfg, weights, mel, z, device, precision=None):
     n, length = z.shape[0], z.shape[1]
     model = IAFVocoder(batch_size=n, length=length, store=store, precision=precision)
     out = model(None, torch.from_numpy(mel).to(device), is_training=False, z=torch.from_numpy(z).to(device))
-    torch.cuda.synchronize()
+    model.verify()          # synchronises; raises PwvRangeError if the split-fp16 range guard fired
     return out.cpu().numpy()
 
 
