@@ -2,7 +2,9 @@
 """bench.py -- throughput of the IAF-WaveNet student generation path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: one process per GPU over RCCL.  Started under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`
+    the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; started plainly (`python bench.py
+    --gpus N`) the script re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.
 
 One "step" = one full forward of the reference-default model (hparams/default.yaml as
 models.py:36-65 builds it: 4 IAF flows, separate scalar + shifter WaveNets = 8 nets, 120
@@ -63,7 +65,21 @@ def parse_args():
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
+    ap.add_argument('--no-f32-exact', action='store_true', help="skip the second timing of the same workload in exact fp32 ('f32_exact')")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def cpu_baseline(case_cfg, target_s):
@@ -134,43 +150,68 @@ def model_algorithmic_work(hp, elem_bytes):
     return nbytes, 2.0 * mac
 
 
+def merged_length(intervals):
+    """Total length of the union of [begin, end] intervals."""
+    total, cur_b, cur_e = 0.0, None, None
+    for b, e in sorted(intervals):
+        if cur_e is None or b > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_b
+            cur_b, cur_e = b, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        total += cur_e - cur_b
+    return total
+
+
+def latest_profile_json(suffix):
+    """Newest profiles/rNN_*<suffix> (the rocprofv3 summaries tools/profile_round.sh commits)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*' + suffix)))
+    return c[-1] if c else None
+
+
 def main():
     args = parse_args()
+    # PWV_BENCH_DRYRUN=control (test hook, tests/test_host_logic.py): no GPU work at all -- the launcher / rendezvous / barrier /
+    # max-over-ranks / rank-0 JSON control flow with a no-op step, over gloo on CPU.
+    # PWV_BENCH_DRYRUN_ONE_GPU=1 (test hook, tests/test_gpu_unfused_and_e2e.py): the real step, but all ranks share GPU 0 and
+    # rendezvous over gloo, to exercise the multi-rank path on a 1-GPU box.
+    control = os.environ.get('PWV_BENCH_DRYRUN') == 'control'
+    dryrun = control or os.environ.get('PWV_BENCH_DRYRUN_ONE_GPU') == '1'
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n' % (args.gpus, world, world))
+    if not control and not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback exists in the product path)')
-    # PWV_BENCH_DRYRUN_ONE_GPU=1 (test hook, tests/test_gpu_unfused_and_e2e.py): all ranks share GPU 0 and rendezvous over
-    # gloo, to exercise the multi-rank control flow (build / barrier / max-over-ranks / rank-0 JSON) on a 1-GPU box
-    dryrun = os.environ.get('PWV_BENCH_DRYRUN_ONE_GPU') == '1'
-    dev_index = 0 if dryrun else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
+    if control:
+        dev = torch.device('cpu')
+    else:
+        dev_index = 0 if dryrun else local_rank
+        torch.cuda.set_device(dev_index)
+        dev = torch.device('cuda', dev_index)
     dist = None
+    backend = None
     if world > 1:
         # keep stdout to the one JSON line: RCCL's version banner (NCCL_DEBUG=VERSION/INFO) would land there
         if os.environ.get('NCCL_DEBUG', '').upper() in ('VERSION', 'INFO', ''):
             os.environ['NCCL_DEBUG'] = 'WARN'
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = 'gloo' if dryrun else 'nccl'                              # 'nccl' IS RCCL on ROCm (xGMI)
         if dryrun:
             dist.init_process_group(backend='gloo')
         else:
-            dist.init_process_group(backend='nccl', device_id=dev)       # RCCL over xGMI
+            dist.init_process_group(backend='nccl', device_id=dev)
     n_gpus = world
 
-    from oracle.iaf_oracle import ModelConfig
-    from pwv_amd import _lib, engine
     from pwv_amd.hparam import hparam as hp
-    from pwv_amd.models import IAFVocoder
-    from pwv_amd.variables import VariableStore
-    if local_rank == 0:
-        _lib.build_library()          # one builder per node; the others wait (no concurrent hipcc on one .so)
-    if dist is not None:
-        dist.barrier()
-
     hp.set_hparam_yaml(args.case)
     length = args.length or hp.generate.length
     utts = args.utts or hp.generate.batch_size
@@ -178,82 +219,131 @@ def main():
         utts = max(1, hp.generate.batch_size // 8)       # 64 utterances over 8 GPUs: 8 per GPU
     hop, n_mels = hp.signal.hop_length, hp.signal.n_mels
     t_mel = 1 + length // hop
-
-    # synthetic, seeded per rank: mel ~ U(-1,1); random-init weights (glorot + N(0,0.1) biases) so bias paths run
-    store = VariableStore(device=dev, seed=2)
-    model = IAFVocoder(batch_size=utts, length=length, store=store, precision=args.precision)
-    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
-    mel = (torch.rand((utts, t_mel, n_mels), generator=g) * 2 - 1).to(dev)
-    model.noise_seed = 1 + rank
-    out = model(None, mel, is_training=False)            # creates + packs the weights
-    for name in list(store.vars):
-        if store.vars[name].dim() == 1:
-            store.vars[name].normal_(0, 0.1, generator=None)
-    store.version += 1
-    engine.clear_plan_cache()
-
-    def eager_step():
-        return model(None, mel, is_training=False)
-
-    if args.no_graph:
-        step = eager_step
-    else:
-        # the same launches, captured once into a HIP graph (pwv_amd/graph.py); each step = one eager noise-sampling
-        # kernel (fresh logistic noise every step) + the mel copy + one graph replay
-        from pwv_amd.graph import GraphedVocoder
-        try:
-            graphed = GraphedVocoder(model)
-
-            def step():
-                return graphed(mel)
-        except Exception as e:      # never lose the measurement to a capture problem: same launches, host-enqueued
-            sys.stderr.write('graph capture failed (%s: %s); falling back to host-enqueued launches\n' % (type(e).__name__, e))
-            args.no_graph = True
-            torch.cuda.synchronize()
-            step = eager_step
+    rows = utts * length
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not control:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not control:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dryrun else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    mel = (torch.rand((utts, t_mel, n_mels), generator=g) * 2 - 1).to(dev)
+    if control:
+        def make_step(precision):
+            return (lambda: torch.zeros((utts, length, 1))), None, False
+    else:
+        from pwv_amd import _lib, engine
+        from pwv_amd.models import IAFVocoder
+        from pwv_amd.variables import VariableStore
+        if local_rank == 0:
+            _lib.build_library()          # one builder per node; the others wait (no concurrent hipcc on one .so)
+        if dist is not None:
+            dist.barrier()
+        # synthetic, seeded per rank: mel ~ U(-1,1); random-init weights (glorot + N(0,0.1) biases) so bias paths run
+        store = VariableStore(device=dev, seed=2)
+        model0 = IAFVocoder(batch_size=utts, length=length, store=store, precision=args.precision)
+        model0.noise_seed = 1 + rank
+        model0(None, mel, is_training=False)            # creates the variables
+        for name in list(store.vars):
+            if store.vars[name].dim() == 1:
+                store.vars[name].normal_(0, 0.1, generator=None)
+        store.version += 1
+        engine.clear_plan_cache()
+
+        def make_step(precision):
+            """(step, eager_step, graphed?) for the model in `precision`; one step = fresh logistic noise + the forward"""
+            model = model0 if precision == args.precision else IAFVocoder(batch_size=utts, length=length, store=store, precision=precision)
+            model.noise_seed = 1 + rank
+
+            def eager_step():
+                return model(None, mel, is_training=False)
+
+            if args.no_graph:
+                return eager_step, eager_step, False
+            # the same launches, captured once into a HIP graph (pwv_amd/graph.py); each step = one eager noise-sampling
+            # kernel (fresh logistic noise every step) + the mel copy + one graph replay
+            from pwv_amd.graph import GraphedVocoder
+            try:
+                graphed = GraphedVocoder(model)
+                return (lambda: graphed(mel)), eager_step, True
+            except Exception as e:      # never lose the measurement to a capture problem: same launches, host-enqueued
+                sys.stderr.write('graph capture failed (%s: %s); falling back to host-enqueued launches\n' % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                return eager_step, eager_step, False
+
+    def timed(step, warmup, steps):
+        out = None
+        for _ in range(warmup):
+            out = step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dryrun else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, out
+
+    step, eager_step, graphed = make_step(args.precision)
+    elapsed, out = timed(step, args.warmup, args.steps)
     assert torch.isfinite(out).all(), 'non-finite output'
+    if not control:
+        model0.verify()          # range guard of the split-fp16 arithmetic (raises if the forward left fp16's range)
 
-    # ---- live kernel timing of the dominant kernel (HIP events on the launch stream) -------------------
-    engine.EVENT_LOG = []
-    for _ in range(max(1, min(args.steps, 5))):
-        eager_step()
-    torch.cuda.synchronize()
-    log, engine.EVENT_LOG = engine.EVENT_LOG, None
-    # each entry: one chain's run of `cnt` back-to-back residual-layer launches between two HIP events
-    chains = [(e0.elapsed_time(e1), cnt, g) for tag, e0, e1, g, cnt in log if tag == 'layer_residual']
-    res_ms = [ms / cnt for ms, cnt, g in chains for _ in range(cnt)]
-    nets_per_launch_timed = chains[0][2]
-    layer_ms = float(np.mean(res_ms))
-    rows = utts * length
-    nets_per_flow = 1 if bool(hp.model.get('shared_nets', False)) else 2
-    nets_per_launch = nets_per_launch_timed
-    # scalar / shifter chains on two streams: `concurrent` launches of this kernel share the chip at any time
-    concurrent = nets_per_flow // nets_per_launch
-    flop_per_launch = rows * nets_per_launch * LAYER_FLOP_PER_SAMPLE
-    bytes_per_launch = rows * nets_per_launch * (LAYER_BYTES_PER_SAMPLE // 2 if args.precision == 'f16' else LAYER_BYTES_PER_SAMPLE)
-    ach_tf = concurrent * flop_per_launch / (layer_ms * 1e-3) / 1e12
-    ach_gbs = concurrent * bytes_per_launch / (layer_ms * 1e-3) / 1e9
+    # ---- the same workload in the reference's own arithmetic (exact fp32 MFMA), timed the same way ------------------
+    f32_exact = None
+    if args.precision == 'f16x3' and not args.no_f32_exact and not control:
+        step32, _, graphed32 = make_step('f32')
+        n32 = max(3, min(args.steps, 10))
+        e32, out32 = timed(step32, 2, n32)
+        assert torch.isfinite(out32).all()
+        f32_exact = (e32, n32, graphed32)
+        del step32, out32
+
+    # ---- utterance scatter / gather over the job's backend, once, outside the timed loop (N > 1) --------------------
+    sharded = None
+    if dist is not None:
+        from pwv_amd.distributed import generate_sharded
+        total = utts * world
+        coll_dev = torch.device('cpu') if dryrun else dev        # gloo (test hooks) scatters / gathers host tensors only
+        full_mel = (torch.rand((total, t_mel, n_mels), generator=torch.Generator().manual_seed(7)) * 2 - 1).to(coll_dev) if rank == 0 else None
+        if control:
+            fwd = lambda m, zz: torch.zeros((m.shape[0], length, 1))
+        else:
+            def fwd(m, zz):
+                net = model0 if m.shape[0] == utts else IAFVocoder(batch_size=m.shape[0], length=length, store=store, precision=args.precision)
+                return net(None, m.to(dev), is_training=False, z=zz).to(coll_dev)
+        wav = generate_sharded(fwd, full_mel, (t_mel, n_mels), length, coll_dev)
+        if rank == 0:
+            assert tuple(wav.shape) == (total, length, 1) and bool(torch.isfinite(wav).all())
+            sharded = '%d utterances scattered over %d ranks, generated, gathered on rank 0: ok' % (total, world)
+
+    # ---- live kernel timing of the dominant kernel (HIP events on the launch streams) --------------------------------
+    timing = None
+    if not control:
+        engine.EVENT_LOG = []
+        ref = torch.cuda.Event(enable_timing=True)
+        ref.record()
+        for _ in range(max(1, min(args.steps, 5))):
+            eager_step()
+        torch.cuda.synchronize()
+        log, engine.EVENT_LOG = engine.EVENT_LOG, None
+        # each entry: one chain's run of `cnt` back-to-back residual-layer launches between two HIP events
+        chains = [(ref.elapsed_time(e0), ref.elapsed_time(e1), cnt, gnets) for tag, e0, e1, gnets, cnt in log if tag == 'layer_residual']
+        busy = merged_length([(b, e) for b, e, _, _ in chains])
+        total_ms = sum(e - b for b, e, _, _ in chains)
+        launches = sum(cnt for _, _, cnt, _ in chains)
+        timing = {'layer_ms': total_ms / launches, 'launches': launches, 'nets_per_launch': chains[0][3],
+                  'overlap': total_ms / busy if busy > 0 else 1.0}
 
     if rank == 0:
+        nets_per_flow = 1 if bool(hp.model.get('shared_nets', False)) else 2
         total_samples = rows * n_gpus * args.steps
         value = total_samples / elapsed
         n_layers = sum(len(d) for d in hp.model.dilations[:hp.model.n_iaf])
@@ -286,47 +376,65 @@ def main():
                 'case': args.case, 'utterances_per_gpu': utts, 'samples_per_utterance': length,
                 'parallelism': 'utterance-sharded x%d (no data-path collective)' % n_gpus,
                 'noise': 'logistic, sampled on device inside the step',
-                'launch': 'host-enqueued launches' if args.no_graph else 'HIP graph replay of the forward (noise sampled by an eager kernel per step)',
+                'launch': 'HIP graph replay of the forward (noise sampled by an eager kernel per step)' if graphed else 'host-enqueued launches',
             },
         }
-        common = {'avg_launch_ms': layer_ms, 'launches_timed': len(res_ms), 'alg_flop_per_launch': flop_per_launch,
-                  'alg_bytes_per_launch': bytes_per_launch, 'traffic': None,
-                  'concurrent_launches': concurrent,
-                  'note': 'achieved = concurrent_launches x algorithmic work per launch / avg launch duration: the scalar and '
-                          'shifter chains of a flow run side by side on two HIP streams, each launch on half of the CUs'
-                          if concurrent > 1 else 'one launch covers all nets of the flow'}
-        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
-        # MI355X_MICROARCH.md prescribes) are collected offline and committed under profiles/; quoted here only
-        # when they were taken on this exact workload and kernel
-        tpath = os.path.join(ROOT, 'profiles', 'r01_e_hbm_traffic.json')
-        if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            # the PMC passes count bytes per launch of one net; a G = 2 launch (PWV_TWO_STREAMS=0) moves twice that
-            common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
-            common['traffic_source'] = 'profiles/r01_e_hbm_traffic.json'
-        if args.precision == 'f32':
-            # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
-            result['roofline'] = dict(kernel='layer_f32_kernel<8,0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
-                                      bound='mfma', achieved=ach_tf, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                                      frac=ach_tf / PEAK_F32_MFMA_TFLOPS, **common)
-            result['roofline_hbm'] = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                      'frac': ach_gbs / PEAK_HBM_GBS}
-        elif args.precision == 'f16':
-            # fp16 rows: 160 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
-            result['roofline'] = dict(kernel='layer_h16_kernel<0,0> (fused gated-residual layer, fp16 rows, %d nets/launch)' % nets_per_launch,
-                                      bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
-                                      frac=ach_gbs / PEAK_HBM_GBS, **common)
-            result['roofline_mfma'] = {'bound': 'mfma', 'achieved': ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                       'frac': ach_tf / PEAK_F16_MFMA_TFLOPS}
-        else:
-            # split-fp16 MFMA: 3 x 80 = 240 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
-            result['roofline'] = dict(kernel='layer_f16x3_kernel<0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
-                                      bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
-                                      frac=ach_gbs / PEAK_HBM_GBS, **common)
-            result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
-                                       'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
+        if dist is not None:
+            result['rccl_ranks'] = world if backend == 'nccl' else 0
+            result['backend'] = backend
+            result['sharded_generate'] = sharded
+        if control:
+            result['dryrun'] = 'control flow only: no kernels ran, value is meaningless (PWV_BENCH_DRYRUN=control)'
         mb, mf = model_algorithmic_work(hp, 2 if args.precision == 'f16' else 4)
+        if timing is not None:
+            layer_ms, nets_per_launch = timing['layer_ms'], timing['nets_per_launch']
+            # scalar / shifter chains on two streams: the measured overlap of the chains' busy intervals (sum / union) says
+            # how many launches of this kernel share the chip on average
+            concurrent = timing['overlap']
+            flop_per_launch = rows * nets_per_launch * LAYER_FLOP_PER_SAMPLE
+            bytes_per_launch = rows * nets_per_launch * (LAYER_BYTES_PER_SAMPLE // 2 if args.precision == 'f16' else LAYER_BYTES_PER_SAMPLE)
+            ach_tf = concurrent * flop_per_launch / (layer_ms * 1e-3) / 1e12
+            ach_gbs = concurrent * bytes_per_launch / (layer_ms * 1e-3) / 1e9
+            common = {'avg_launch_ms': layer_ms, 'launches_timed': timing['launches'], 'alg_flop_per_launch': flop_per_launch,
+                      'alg_bytes_per_launch': bytes_per_launch, 'traffic': None,
+                      'concurrent_launches': concurrent,
+                      'note': 'achieved = concurrent_launches x algorithmic work per launch / avg launch duration; concurrent_launches is '
+                              'MEASURED: sum of the chains\' event intervals / length of their union (the scalar and shifter chains of a '
+                              'flow run side by side on two HIP streams)' if nets_per_flow // nets_per_launch > 1
+                              else 'one launch covers all nets of the flow'}
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+            # MI355X_MICROARCH.md prescribes) and the rocprofv3 per-kernel average are collected offline and committed under
+            # profiles/; quoted here only when they were taken on this exact workload and kernel
+            tpath = latest_profile_json('_hbm_traffic.json')
+            if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and tpath:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                # the PMC passes count bytes per launch of one net; a G = 2 launch moves twice that
+                common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
+                common['traffic_source'] = os.path.relpath(tpath, ROOT)
+                if 'rocprof_kernel_us' in tj:
+                    common['rocprof_kernel_us'] = tj['rocprof_kernel_us']
+            if args.precision == 'f32':
+                # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
+                result['roofline'] = dict(kernel='layer_f32_kernel (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
+                                          bound='mfma', achieved=ach_tf, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                                          frac=ach_tf / PEAK_F32_MFMA_TFLOPS, **common)
+                result['roofline_hbm'] = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                          'frac': ach_gbs / PEAK_HBM_GBS}
+            elif args.precision == 'f16':
+                # fp16 rows: 160 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
+                result['roofline'] = dict(kernel='layer_h16_kernel<0,0> (fused gated-residual layer, fp16 rows, %d nets/launch)' % nets_per_launch,
+                                          bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
+                                          frac=ach_gbs / PEAK_HBM_GBS, **common)
+                result['roofline_mfma'] = {'bound': 'mfma', 'achieved': ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                           'frac': ach_tf / PEAK_F16_MFMA_TFLOPS}
+            else:
+                # split-fp16 MFMA: 3 x 80 = 240 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
+                result['roofline'] = dict(kernel='layer_f16x3_kernel<0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
+                                          bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
+                                          frac=ach_gbs / PEAK_HBM_GBS, **common)
+                result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
+                                           'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
         per_gpu = value / n_gpus
         result['model'] = {
             'note': 'whole-model algorithmic work per output sample (SURVEY.md section 8d "layer-streaming" model), per GPU',
@@ -335,7 +443,17 @@ def main():
             'alg_TFLOPs': mf * per_gpu / 1e12,
             'vs_fp32_fma_ceiling': per_gpu / (PEAK_F32_MFMA_TFLOPS * 1e12 / mf),
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if f32_exact is not None:
+            e32, n32, g32 = f32_exact
+            v32 = rows * n_gpus * n32 / e32
+            result['f32_exact'] = {
+                'note': "the same workload with precision='f32': v_mfma_f32_32x32x2_f32, the reference's own arithmetic (models.py:81-82); "
+                        'matrix-pipe bound, so its roofline is the fp32 MFMA peak (157.3 TFLOP/s)',
+                'value': v32, 'unit': 'samples/s', 'ms_per_step': e32 / n32 * 1e3, 'steps': n32,
+                'alg_TFLOPs': mf * v32 / n_gpus / 1e12, 'mfma_frac': mf * v32 / n_gpus / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                'launch': 'HIP graph replay' if g32 else 'host-enqueued launches'}
+        if n_gpus == 1 and not args.no_cpu_baseline and not control:
+            from oracle.iaf_oracle import ModelConfig          # the oracle is only ever the CPU leg, never the timed path
             result['cpu_baseline'] = cpu_baseline(ModelConfig.from_hparam(hp), args.cpu_seconds)
         sys.stdout.flush()
         print(json.dumps(result), flush=True)

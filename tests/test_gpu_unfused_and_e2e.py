@@ -225,8 +225,9 @@ def test_graphed_vocoder_matches_eager_bitwise(gpu):
 
 
 def test_bench_multi_rank_control_flow_on_one_gpu():
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the test hook
-    PWV_BENCH_DRYRUN_ONE_GPU=1: both ranks share GPU 0 and rendezvous over gloo.  Checks what does not need N GPUs: every
+    """bench.py for N > 1, both ways it can be started -- under torch.distributed.run (one process per rank) and plainly
+    (`python bench.py --gpus 2`: it then spawns its ranks itself) -- with the test hook PWV_BENCH_DRYRUN_ONE_GPU=1: both
+    ranks share GPU 0 and rendezvous over gloo.  Checks what does not need N GPUs: every
     rank builds / waits, the timed region is bracketed by barriers, rank 0 alone prints ONE JSON line with whole-job
     throughput for n_gpus = 2 and weak scaling."""
     import json
@@ -238,13 +239,17 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     env = dict(os.environ, PWV_BENCH_DRYRUN_ONE_GPU='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--case', 'bench/c1', '--no-cpu-baseline']
-    res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, res.stdout[-2000:]
-    j = json.loads(lines[0])
-    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 3 and j['value'] > 0
-    assert 'utterance-sharded x2' in j['config']['parallelism'] and 'cpu_baseline' not in j
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--case', 'bench/c1', '--no-cpu-baseline']
+    launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                '--master-port', str(port)]
+    for cmd in (launcher + tail, [sys.executable] + tail):
+        res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, res.stdout[-2000:]
+        j = json.loads(lines[0])
+        assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 3 and j['value'] > 0
+        assert 'utterance-sharded x2' in j['config']['parallelism'] and 'cpu_baseline' not in j
+        assert 'scattered over 2 ranks' in j['sharded_generate'] and j['f32_exact']['value'] > 0

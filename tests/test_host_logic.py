@@ -1,5 +1,7 @@
 """CPU: hparam semantics (hparam.py:7-68), the variable store / TF naming, the fire-style CLI
 parser, and that the product path refuses CPU tensors instead of falling back."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,3 +150,24 @@ def test_fire_style_cli_parsing():
     assert seen == dict(case='y', ckpt=None, debug=True)
     _fire(fn, ['--some-flag'.replace('some-flag', 'debug'), '--ckpt', 'a-b'])
     assert seen == dict(case='default', ckpt='a-b', debug=True)
+
+
+def test_bench_spawns_its_own_ranks_when_started_without_a_launcher():
+    """`python bench.py --gpus 2` (the driver's command shape, no torch.distributed.run in front) must start 2 ranks
+    itself, rendezvous, take the max over ranks and print ONE JSON line with n_gpus == 2.  PWV_BENCH_DRYRUN=control
+    swaps the GPU step for a no-op (gloo on CPU) -- the launcher / collective control flow is what is under test."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PWV_BENCH_DRYRUN='control')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
+    assert 'scattered over 2 ranks' in out['sharded_generate'] and 'dryrun' in out
