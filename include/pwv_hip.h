@@ -308,6 +308,42 @@ typedef struct pwv_stack_args {
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);
 
+/* ---------------------------------------------------------------------------------------
+ * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation, no per-sample condition,
+ * PWV_PREC_F16X3) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
+ * (modules.py:138-143) without a kernel boundary, a weight-staging phase and a ramp-up / ramp-down per layer.
+ *   x_in[g]  input of the run's first layer, x_out[g] output of its last layer (both full-size tile32 buffers,
+ *   N*T rows x 64); layer j of the run reads packed_layers[g] + j*packed_layer_stride and the P columns
+ *   proj[g] + 128*j.  Results are bit-identical to n_layers calls of pwv_wavenet_layer_f32.
+ * Each of the chip's 8 XCDs works on its own eighth of the rows (recomputing the x[t-d] halo of the later layers), its
+ * workgroups hand (layer, unit) tasks to each other through flags in `workspace`; csrc/pwv_stack_persist.hip has the
+ * protocol.  The call enqueues a memset of the workspace's control words and one kernel (grid = one workgroup per CU).
+ *   pwv_persist_workspace_bytes   size of `workspace` (device memory, 256-byte aligned, contents don't care)
+ *   pwv_persist_status(&p)        process-wide sticky int32 in pinned host memory: 0, or != 0 once a launch gave up
+ *                                 (a workgroup placement it was not planned for, or a poll that ran into its bound);
+ *                                 the outputs of that launch are then invalid and the caller uses the per-layer path.
+ * Use it for N*T large enough that every XCD has more units than waves (N*T >= 2^16 at G = 2).
+ * ------------------------------------------------------------------------------------- */
+typedef struct pwv_persist_args {
+    int G;
+    int n_layers;                                 /* 2..32 layers in this launch */
+    const int* dilations;                         /* HOST array [n_layers] */
+    const float* x_in[PWV_MAX_NETS];
+    float* x_out[PWV_MAX_NETS];
+    const float* packed_layers[PWV_MAX_NETS];     /* the run's first layer */
+    size_t packed_layer_stride;
+    const float* proj[PWV_MAX_NETS];              /* the run's first layer's columns */
+    int proj_row_stride;
+    int N, T;
+    int cond_hop, cond_offset, cond_frames;
+    void* workspace;
+    size_t workspace_bytes;
+} pwv_persist_args;
+
+size_t pwv_persist_workspace_bytes(int G, int N, int T, int n_layers, const int* dilations);
+int pwv_persist_status(int** status);
+int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,8 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int64, c_size_t, c_uin
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_ROOT = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so')   # PWV_LIB: A/B another build
-CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip')]
+CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip',
+                                                    'pwv_stack_persist.hip')]
 
 PWV_MAX_NETS = 2
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
@@ -30,6 +31,7 @@ EXPORTED_SYMBOLS = (
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
     'pwv_linear_split_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_range_check_f32',
+    'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32',
 )
 
 
@@ -113,9 +115,27 @@ class StackArgs(Structure):
     ]
 
 
+class PersistArgs(Structure):
+    _fields_ = [
+        ('G', c_int),
+        ('n_layers', c_int),
+        ('dilations', POINTER(c_int)),
+        ('x_in', c_void_p * PWV_MAX_NETS),
+        ('x_out', c_void_p * PWV_MAX_NETS),
+        ('packed_layers', c_void_p * PWV_MAX_NETS),
+        ('packed_layer_stride', c_size_t),
+        ('proj', c_void_p * PWV_MAX_NETS),
+        ('proj_row_stride', c_int),
+        ('N', c_int), ('T', c_int),
+        ('cond_hop', c_int), ('cond_offset', c_int), ('cond_frames', c_int),
+        ('workspace', c_void_p),
+        ('workspace_bytes', c_size_t),
+    ]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into the in-tree shared library."""
-    srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', 'pwv_common.h'), os.path.join(_PKG_DIR, 'csrc', 'pwv_layer_common.h'), os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
+    srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', h) for h in ('pwv_common.h', 'pwv_layer_common.h', 'pwv_f16x3.h')] + [os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
     if os.environ.get('PWV_LIB'):
         return LIB_PATH            # an explicitly chosen library is never rebuilt
     if not force and os.path.exists(LIB_PATH):
@@ -167,6 +187,10 @@ def _declare(lib):
     lib.pwv_pack_head_f32.argtypes = [f32p] * 6 + [c_int, c_int, f32p, c_void_p]
     lib.pwv_wavenet_head_f32.argtypes = [POINTER(HeadArgs), c_void_p]
     lib.pwv_wavenet_stack_f32.argtypes = [POINTER(StackArgs), POINTER(c_void_p)]
+    lib.pwv_persist_workspace_bytes.restype = c_size_t
+    lib.pwv_persist_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int)]
+    lib.pwv_persist_status.argtypes = [POINTER(c_void_p)]
+    lib.pwv_wavenet_stack_persist_f32.argtypes = [POINTER(PersistArgs), c_void_p]
     lib.pwv_range_flag.argtypes = [POINTER(c_void_p)]
     lib.pwv_range_check_f32.argtypes = [f32p, c_int64, ctypes.c_float, c_void_p, c_void_p]
     for name in EXPORTED_SYMBOLS:      # fails loudly (AttributeError) if a symbol is missing

@@ -49,7 +49,47 @@ TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
 FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
 # PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
 FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
+# PWV_PERSIST=0: always one launch per layer.  Default: the residual layers 1 .. L-2 of a stack run as ONE persistent
+# dataflow launch (csrc/pwv_stack_persist.hip) whenever the input is large enough for it (bit-identical results).
+PERSIST = os.environ.get('PWV_PERSIST', '1') != '0'
+# units per XCD (and net) the persistent launch wants per wave sharing them.  Below ~2 the per-layer launches are as fast
+# (and claims start to span layers); tests set 0 to force the persistent path onto small inputs.
+PERSIST_UNITS_PER_WAVE = float(os.environ.get('PWV_PERSIST_UNITS_PER_WAVE', '2'))
+_persist_status_addr = None
 _side_streams = {}
+
+
+def persist_status() -> int:
+    """The library's sticky status word of the persistent stack kernel (pinned host memory): 0 = every launch that has
+    completed so far ran to its end; otherwise a launch gave up and its outputs are invalid."""
+    global _persist_status_addr
+    if _persist_status_addr is None:
+        p = c_void_p()
+        check(_lib.lib().pwv_persist_status(ctypes.byref(p)), 'pwv_persist_status')
+        _persist_status_addr = p.value
+    return ctypes.c_int.from_address(_persist_status_addr).value
+
+
+def raise_if_persist_failed() -> None:
+    """A give-up of the persistent kernel (unexpected workgroup placement, a poll that ran into its bound) switches the
+    process to the per-layer path and raises: the caller reruns the forward."""
+    global PERSIST
+    code = persist_status()
+    if code != 0:
+        ctypes.c_int.from_address(_persist_status_addr).value = 0
+        PERSIST = False
+        raise _lib.PwvError('the persistent stack kernel gave up (code %d); its outputs are invalid -- the per-layer path is '
+                            'used from now on, rerun the forward' % code)
+
+
+def _persist_fits(G: int, rows: int, L: int) -> bool:
+    cus = _lib.lib().pwv_device_cus()
+    if L < 4 or cus < 8 or cus % 8 or (cus // 8) % G:
+        return False
+    units = (rows + 31) // 32
+    upx = (units + 7) // 8
+    waves = 8 * (cus // 8 // G)
+    return units >= 64 and min(upx, units - 7 * upx) >= max(1.0, PERSIST_UNITS_PER_WAVE * waves)
 
 
 def _net_streams(device):
@@ -306,6 +346,71 @@ def _same_structure(a, b) -> bool:
             and a.condition_channels == b.condition_channels and a.filter_width == b.filter_width)
 
 
+def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s):
+    """Layer 0 (one launch), layers 1 .. L-2 (ONE persistent launch), layer L-1 with the head behind it (one launch); all
+    nets of the flow in every launch, all on the current stream."""
+    G, L = len(nets), plans[0].n_layers
+    net0 = nets[0]
+    hop, offset, frames = cond_geom
+    stride = plans[0].layer_floats
+
+    def layer_args(j, src, dst):
+        la = _lib.LayerArgs()
+        la.G = G
+        for g in range(G):
+            la.x_in[g], la.x_out[g] = bufs[g][src].data_ptr(), bufs[g][dst].data_ptr()
+            la.packed[g] = plans[g].packed_layers.data_ptr() + 4 * stride * j
+            la.proj[g] = projs[g].data_ptr() + 4 * 128 * j
+        la.proj_row_stride = row_stride
+        la.skip_init = 1
+        la.N, la.T, la.dilation = n, t, int(net0.dilations[j])
+        la.cond_hop, la.cond_offset, la.cond_frames = hop, offset, frames
+        la.precision = _lib.PREC_F16X3
+        return la
+
+    la = layer_args(0, 0, 1)
+    la.out_mode = _lib.OUT_RESIDUAL
+    if x_first is not None:
+        la.x_first, la.x_limit, la.range_flag = _ptr(x_first), x_limit, range_flag_ptr()
+        for g in range(G):
+            la.causal_filter[g] = plans[g].causal_filter.data_ptr()
+    check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
+
+    pa = _lib.PersistArgs()
+    pa.G, pa.n_layers = G, L - 2
+    dil = (ctypes.c_int * (L - 2))(*[int(d) for d in net0.dilations[1:L - 1]])
+    pa.dilations = dil
+    for g in range(G):
+        pa.x_in[g], pa.x_out[g] = bufs[g][1].data_ptr(), bufs[g][0].data_ptr()
+        pa.packed_layers[g] = plans[g].packed_layers.data_ptr() + 4 * stride
+        pa.proj[g] = projs[g].data_ptr() + 4 * 128
+    pa.packed_layer_stride = stride
+    pa.proj_row_stride = row_stride
+    pa.N, pa.T = n, t
+    pa.cond_hop, pa.cond_offset, pa.cond_frames = hop, offset, frames
+    nbytes = lib.pwv_persist_workspace_bytes(G, n, t, L - 2, dil)
+    if nbytes == 0:
+        raise _lib.PwvError('pwv_persist_workspace_bytes: %s' % lib.pwv_last_error().decode())
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=bufs[0][0].device)
+    pa.workspace, pa.workspace_bytes = ws.data_ptr(), nbytes
+    ev = None
+    if EVENT_LOG is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
+    if ev is not None:
+        ev[1].record()
+        EVENT_LOG.append(('persist', ev[0], ev[1], G, L - 2))
+
+    la = layer_args(L - 1, 0, 1)
+    la.out_mode = _lib.OUT_GATED
+    for g in range(G):
+        la.head_packed[g] = plans[g].packed_head.data_ptr()
+        la.head_out[g] = outs[g].data_ptr()
+    la.head_q = net0.out_channels
+    check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
+
+
 def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,
              max_workgroups: int = 0) -> List[torch.Tensor]:
     """Evaluate 1 or 2 structurally identical fused-capable WaveNets on the same input/condition.
@@ -393,7 +498,10 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
 
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
     main = torch.cuda.current_stream()
-    two = G == 2 and TWO_STREAMS and max_workgroups == 0
+    use_skip = bool(net0.use_skip_connection)
+    persist = (PERSIST and prec == _lib.PREC_F16X3 and mode != 'samples' and not use_skip and max_workgroups == 0 and FUSE_HEAD
+               and _persist_fits(G, rows, L))
+    two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
     if mode == 'frames':
         f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames_per_utt, -1)
@@ -436,11 +544,14 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             check(lib.pwv_rows_to_tile32_f32(_ptr(hrows), _ptr(bufs[g][0]), rows, R, s), 'pwv_rows_to_tile32_f32')
 
 
-    use_skip = bool(net0.use_skip_connection)
     skips = [tile_buf(net0.skip_channels) for _ in nets] if use_skip else None
     Q = net0.out_channels
     outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
 
+    if persist:
+        _run_stack_persist(lib, nets, plans, projs, bufs, outs, x if first_fused else None, x_limit, row_stride,
+                           (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s)
+        return outs
     if two:
         for g in range(2):
             side[g].wait_stream(main)

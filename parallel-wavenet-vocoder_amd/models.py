@@ -51,7 +51,8 @@ class IAFVocoder(object):
         GPU.  ``z`` (optional, [N, length, 1]) replaces the logistic noise sampled at
         models.py:32-33 so results are reproducible against the oracle."""
         store = self.store or get_default_store()
-        engine.raise_if_range_flag('an earlier call')       # sticky flag of a forward that has completed since
+        engine.raise_if_range_flag('an earlier call')       # sticky flags of forwards that have completed since
+        engine.raise_if_persist_failed()
         melspec = engine._require_cuda_f32(melspec, 'melspec')
         if melspec.dim() != 3 or melspec.shape[1] != self.t_mel or melspec.shape[2] != hp.signal.n_mels:
             raise ValueError('melspec must be [N, %d, %d], got %s' % (self.t_mel, hp.signal.n_mels, tuple(melspec.shape)))
@@ -106,6 +107,7 @@ class IAFVocoder(object):
         arithmetic (the reference computes in fp32, models.py:81-82; see include/pwv_hip.h "Range guard")."""
         import torch
         torch.cuda.synchronize()
+        engine.raise_if_persist_failed()
         engine.raise_if_range_flag()
 
     def _mel_limit(self, weights, store):
