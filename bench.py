@@ -334,13 +334,21 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         log, engine.EVENT_LOG = engine.EVENT_LOG, None
-        # each entry: one chain's run of `cnt` back-to-back residual-layer launches between two HIP events
+        # entries: ('layer_residual', ...) one chain's run of `cnt` back-to-back per-layer launches between two HIP events;
+        #          ('persist', ...) ONE persistent launch covering `cnt` layers of `gnets` nets
+        pers = [(ref.elapsed_time(e0), ref.elapsed_time(e1), cnt, gnets) for tag, e0, e1, gnets, cnt in log if tag == 'persist']
         chains = [(ref.elapsed_time(e0), ref.elapsed_time(e1), cnt, gnets) for tag, e0, e1, gnets, cnt in log if tag == 'layer_residual']
-        busy = merged_length([(b, e) for b, e, _, _ in chains])
-        total_ms = sum(e - b for b, e, _, _ in chains)
-        launches = sum(cnt for _, _, cnt, _ in chains)
-        timing = {'layer_ms': total_ms / launches, 'launches': launches, 'nets_per_launch': chains[0][3],
-                  'overlap': total_ms / busy if busy > 0 else 1.0}
+        if pers:
+            total_ms = sum(e - b for b, e, _, _ in pers)
+            timing = {'kind': 'persist', 'launches': len(pers), 'total_ms': total_ms, 'net_layers': sum(cnt * g for _, _, cnt, g in pers),
+                      'launch_ms': [min(e - b for b, e, _, _ in pers), max(e - b for b, e, _, _ in pers)],
+                      'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3]}
+        elif chains:
+            busy = merged_length([(b, e) for b, e, _, _ in chains])
+            total_ms = sum(e - b for b, e, _, _ in chains)
+            launches = sum(cnt for _, _, cnt, _ in chains)
+            timing = {'kind': 'per-layer', 'layer_ms': total_ms / launches, 'launches': launches, 'nets_per_launch': chains[0][3],
+                      'overlap': total_ms / busy if busy > 0 else 1.0}
 
     if rank == 0:
         nets_per_flow = 1 if bool(hp.model.get('shared_nets', False)) else 2
@@ -386,13 +394,41 @@ def main():
         if control:
             result['dryrun'] = 'control flow only: no kernels ran, value is meaningless (PWV_BENCH_DRYRUN=control)'
         mb, mf = model_algorithmic_work(hp, 2 if args.precision == 'f16' else 4)
-        if timing is not None:
+        layer_bytes = LAYER_BYTES_PER_SAMPLE // 2 if args.precision == 'f16' else LAYER_BYTES_PER_SAMPLE
+        if timing is not None and timing['kind'] == 'persist':
+            # the dominant kernel is the persistent stack kernel: one launch runs `layers` residual layers of both nets of a flow
+            alg_bytes = rows * timing['net_layers'] * layer_bytes          # over all timed launches
+            alg_flop = rows * timing['net_layers'] * LAYER_FLOP_PER_SAMPLE
+            ach_gbs = alg_bytes / (timing['total_ms'] * 1e-3) / 1e9
+            ach_tf = alg_flop / (timing['total_ms'] * 1e-3) / 1e12
+            roof = {'kernel': 'stack_persist_kernel (persistent dataflow launch: %s residual layers x %d nets per launch, split-fp16 MFMA)'
+                              % ('/'.join(str(c) for c in timing['layers_per_launch']), timing['nets_per_launch']),
+                    'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS,
+                    'launches_timed': timing['launches'], 'launch_ms_min_max': timing['launch_ms'],
+                    'us_per_layer_pair': timing['total_ms'] * 1e3 / (timing['net_layers'] / timing['nets_per_launch']),
+                    'alg_bytes_per_net_layer': rows * layer_bytes, 'alg_flop_per_net_layer': rows * LAYER_FLOP_PER_SAMPLE,
+                    'traffic': None,
+                    'note': 'achieved = algorithmic bytes (512 B per sample, net and layer) of the layers a launch runs / its duration, '
+                            'HIP events around each persistent launch on its stream (all timed launches pooled)'}
+            tpath = latest_profile_json('_hbm_traffic.json')
+            if args.case == 'bench/c3' and rows == 160000 and tpath:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get('kernel', '').startswith('stack_persist') or 'stack_persist' in tj.get('kernel', ''):
+                    roof['traffic'] = tj['traffic_bytes_per_net_layer']
+                    roof['traffic_source'] = os.path.relpath(tpath, ROOT)
+                    if 'rocprof_kernel_us' in tj:
+                        roof['rocprof_kernel_us'] = tj['rocprof_kernel_us']
+            result['roofline'] = roof
+            result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS,
+                                       'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)', 'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
+        elif timing is not None:
             layer_ms, nets_per_launch = timing['layer_ms'], timing['nets_per_launch']
             # scalar / shifter chains on two streams: the measured overlap of the chains' busy intervals (sum / union) says
             # how many launches of this kernel share the chip on average
             concurrent = timing['overlap']
             flop_per_launch = rows * nets_per_launch * LAYER_FLOP_PER_SAMPLE
-            bytes_per_launch = rows * nets_per_launch * (LAYER_BYTES_PER_SAMPLE // 2 if args.precision == 'f16' else LAYER_BYTES_PER_SAMPLE)
+            bytes_per_launch = rows * nets_per_launch * layer_bytes
             ach_tf = concurrent * flop_per_launch / (layer_ms * 1e-3) / 1e12
             ach_gbs = concurrent * bytes_per_launch / (layer_ms * 1e-3) / 1e9
             common = {'avg_launch_ms': layer_ms, 'launches_timed': timing['launches'], 'alg_flop_per_launch': flop_per_launch,
@@ -402,18 +438,14 @@ def main():
                               'MEASURED: sum of the chains\' event intervals / length of their union (the scalar and shifter chains of a '
                               'flow run side by side on two HIP streams)' if nets_per_flow // nets_per_launch > 1
                               else 'one launch covers all nets of the flow'}
-            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
-            # MI355X_MICROARCH.md prescribes) and the rocprofv3 per-kernel average are collected offline and committed under
-            # profiles/; quoted here only when they were taken on this exact workload and kernel
             tpath = latest_profile_json('_hbm_traffic.json')
             if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and tpath:
                 with open(tpath) as f:
                     tj = json.load(f)
-                # the PMC passes count bytes per launch of one net; a G = 2 launch moves twice that
-                common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
-                common['traffic_source'] = os.path.relpath(tpath, ROOT)
-                if 'rocprof_kernel_us' in tj:
-                    common['rocprof_kernel_us'] = tj['rocprof_kernel_us']
+                if 'traffic_bytes_per_launch' in tj:
+                    # the PMC passes count bytes per launch of one net; a G = 2 launch moves twice that
+                    common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
+                    common['traffic_source'] = os.path.relpath(tpath, ROOT)
             if args.precision == 'f32':
                 # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
                 result['roofline'] = dict(kernel='layer_f32_kernel (fused gated-residual layer, %d nets/launch)' % nets_per_launch,

@@ -310,8 +310,9 @@ __global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsign
     s = (s ^ (s >> 30)) * 0xBF58476D1CE4E5B9ull;
     s = (s ^ (s >> 27)) * 0x94D049BB133111EBull;
     s = s ^ (s >> 31);
-    // 24 random bits -> u in (0,1), never 0 or 1
-    const float u = ((float)(unsigned)(s >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    // 23 random bits -> u in [2^-24, 1 - 2^-24]: k + 0.5 is exact in fp32 for k < 2^23, so u is never 0 or 1 (with 24 bits
+    // 16777215.5 rounds up to 2^24, u = 1 and z = +inf once in 2^24 samples -- found by the split-fp16 range guard)
+    const float u = ((float)(unsigned)(s >> 41) + 0.5f) * (1.0f / 8388608.0f);
     z[i] = logf(u) - log1pf(-u);
 }
 

@@ -36,7 +36,7 @@ constexpr int kSlot = kA1Size + kA2Size;   // floats per LDS half: filter|gate (
 constexpr int kRing = 3;                   // strip buffers per (net, XCD)
 constexpr int kMaxPLayers = 32;
 constexpr int kSpinLimit = 1 << 17;        // polls before a wave gives up (~0.1-0.3 s)
-constexpr int kCtlWg = 64;                 // ints of control state per workgroup: [0] loaded, [1 + j] done[j]
+constexpr int kCtlWg = 64;                 // ints of control state per workgroup: [p] newest layer resident in LDS half p, [2 + j] done[j]
 constexpr int kCtlXcd = 64;                // ints of control state per XCD (own cache lines): [0] workgroup slot counter, [16 + 16 g] task counter of net g
 constexpr int kCtlHead = 8 * kCtlXcd;      // ints in front of the per-workgroup blocks
 
@@ -86,12 +86,19 @@ __device__ __forceinline__ int ld_word(const int* p) {
 __device__ __forceinline__ void st_word(int* p, int v, int lane) {
     if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#ifdef PWV_PTRACE
+static __device__ long long* g_diag_base = nullptr;
+#define g_diag (g_diag_base ? g_diag_base + (size_t)(2048 + blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 : nullptr)
+#endif
 __device__ __forceinline__ bool spin_ge(const int* p, int need, int* status, int code, int lane) {
     for (int k = 0; k < kSpinLimit; ++k) {
         if (ld_word(p) >= need) return true;
         __builtin_amdgcn_s_sleep(8);
     }
     if (lane == 0) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef PWV_PTRACE
+    if (lane == 0 && g_diag) { g_diag[0] = code; g_diag[1] = need; g_diag[2] = ld_word(p); g_diag[3] = (long long)p; }
+#endif
     return false;
 }
 
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     __shared__ __attribute__((aligned(16))) float lds[2 * kSlot];
 #ifdef PWV_PTRACE
     const long long pt_entry_rt = __builtin_amdgcn_s_memrealtime();      // 100 MHz, chip-wide
+    g_diag_base = p.trace;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -114,16 +122,24 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     __syncthreads();
     const int slot = __builtin_amdgcn_readfirstlane(lds_i[0]);
     __syncthreads();
-    if (slot >= p.wpx * p.G) {      // more workgroups on this XCD than the plan has slots for: refuse, loudly
-        if (tid == 0) __hip_atomic_store(p.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
+    // The dispatcher usually puts gridDim / 8 workgroups on every XCD, but it is free not to (CUs still held by the previous
+    // kernel's tail, a concurrent stream): however many arrive here, they alternate between the nets and share the XCD's
+    // tasks dynamically.  What must hold is that every net has at least one workgroup on every XCD: the exit census checks it.
     const int net = slot % p.G;
     const int wgi = slot / p.G;
-    int* wgctl = p.ctl + kCtlHead + (xcc * p.wpx * p.G + slot) * kCtlWg;
+    int* wgctl = p.ctl + kCtlHead + blockIdx.x * kCtlWg;
     int* task_ctr = p.ctl + xcc * kCtlXcd + 16 + 16 * net;     // next unclaimed task of this (XCD, net)
     const int w = wgi * 8 + wave;
     const int L = p.n_layers;
+    // the per-layer tables live in two VGPRs (lane j holds entry j) and are read with v_readlane: a dynamically indexed
+    // kernel argument is a scalar LOAD plus a wait each time, and the task bookkeeping at the top of every unit needs ~10
+    const int v_dil = p.dil[lane & (kMaxPLayers - 1)], v_hu = p.hu[lane & (kMaxPLayers - 1)];
+    auto dil_of = [&](int j) -> int { return __builtin_amdgcn_readlane(v_dil, j); };
+    auto hu_of = [&](int j) -> int { return __builtin_amdgcn_readlane(v_hu, j); };
+    const float* const proj_n = p.proj[net];
+    const float* const packed_n = p.packed[net];
+    const float* const xin_n = p.x_in[net];
+    float* const xout_n = p.x_out[net];
 
     // ---- weights of the first two layers (LDS-DMA, packed order == LDS order) ---------------------------------------
     fill_lds_dma<kSlot / 4, 8>(lds, p.packed[net], wave, lane);
@@ -135,14 +151,24 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     const int rows = p.N * p.T;
     const int own_lo = xcc * p.upx;
     const int hi = own_lo + p.upx < p.units ? own_lo + p.upx : p.units;
-    if (own_lo >= hi) return;
-    const int strip_u0 = own_lo - p.hu[0];                        // unit held by strip position 0 (may be negative)
+    // exit census: the last workgroup of the grid to get here checks that every XCD that owns rows had >= G workgroups
+    auto census = [&]() {
+        __syncthreads();
+        if (tid != 0) return;
+        const int done_wgs = __hip_atomic_fetch_add(&p.ctl[kCtlXcd - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done_wgs != (int)gridDim.x - 1) return;
+        for (int x = 0; x < 8; ++x)
+            if (x * p.upx < p.units && __hip_atomic_load(&p.ctl[x * kCtlXcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.G)
+                __hip_atomic_store(p.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    if (own_lo >= hi) { census(); return; }
+    const int strip_u0 = own_lo - hu_of(0);                        // unit held by strip position 0 (may be negative)
     int* flags = p.flags[net] + (size_t)xcc * p.strip_units - strip_u0;      // indexed by GLOBAL unit
     float* strip_base = p.strips[net] + (size_t)xcc * kRing * p.strip_units * 2048;
     const unsigned strip_bytes = (unsigned)p.strip_units * 8192u;
     const unsigned full_bytes = (unsigned)(((long long)rows + 31) / 32) * 8192u;
 
-    auto lo_of = [&](int j) -> int { const int v = own_lo - p.hu[j]; return v > 0 ? v : 0; };
+    auto lo_of = [&](int j) -> int { const int v = own_lo - hu_of(j); return v > 0 ? v : 0; };
     // task index -> (layer, unit); pure function of i (round-robin, layer-major)
     auto locate = [&](int i, int& j, int& base) -> int {
         while (j < L && i >= base + (hi - lo_of(j))) { base += hi - lo_of(j); ++j; }
@@ -160,12 +186,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const bool first = j == 0;
         const int slotj = first ? 0 : (j - 1) % kRing;
         shift = first ? 0 : 32 * strip_u0;
-        return make_rsrc(first ? p.x_in[net] : strip_base + (size_t)slotj * p.strip_units * 2048, first ? full_bytes : strip_bytes);
+        return make_rsrc(first ? xin_n : strip_base + (size_t)slotj * p.strip_units * 2048, first ? full_bytes : strip_bytes);
     };
     auto out_rsrc = [&](int j, int& shift) -> __amdgpu_buffer_rsrc_t {
         const bool last = j == L - 1;
         shift = last ? 0 : 32 * strip_u0;
-        return make_rsrc(last ? p.x_out[net] : strip_base + (size_t)(j % kRing) * p.strip_units * 2048, last ? full_bytes : strip_bytes);
+        return make_rsrc(last ? xout_n : strip_base + (size_t)(j % kRing) * p.strip_units * 2048, last ? full_bytes : strip_bytes);
     };
     // byte offset of lane (row, h)'s first 16-byte chunk inside a tile32 buffer whose row 0 is global row `shift`
     auto toff = [&](int row, int shift) -> int { const int r = row - shift; return ((r >> 5) * 2048 + h * 128 + (r & 31) * 4) * 4; };
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         bool valid;
         unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
         const __amdgpu_buffer_rsrc_t r = in_rsrc(j, shift);
-        const int d = p.dil[j];
+        const int d = dil_of(j);
         const bool has_prev = t >= d;
         const int oc = toff(rc, shift), ob = toff(has_prev ? rc - d : rc, shift);
 #pragma unroll
@@ -203,12 +229,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     struct Deps { int ra, rb, rc, raw_need, wa, wb, war_need; };      // flag indices (global units) and required counts
     auto deps_of = [&](int j, int u) -> Deps {
         Deps q;
-        const int d = p.dil[j];
+        const int d = dil_of(j);
         const int ua = (32 * u - d) >> 5, ub = (32 * u + 31 - d) >> 5;
         q.ra = u; q.rb = ua < 0 ? u : ua; q.rc = ub < 0 ? u : ub;
         q.raw_need = j;                                   // j == 0: always satisfied (flags start at 0)
         q.war_need = (j >= kRing && j < L - 1) ? j - 1 : 0;
-        const int d2 = p.dil[j >= 2 ? j - 2 : 0];
+        const int d2 = dil_of(j >= 2 ? j - 2 : 0);
         const int wa = u + (d2 >> 5), wb = u + ((d2 + 31) >> 5);
         q.wa = wa > hi - 1 ? u : wa; q.wb = wb > hi - 1 ? u : wb;
         return q;
@@ -226,18 +252,18 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     auto flush_owed = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (prev_u >= 0) { st_word(flags + prev_u, prev_j + 1, lane); prev_u = -1; }
-        if (dma_pending >= 0) { st_word(&wgctl[0], dma_pending, lane); dma_pending = -1; }
+        if (dma_pending >= 0) { st_word(&wgctl[dma_pending & 1], dma_pending, lane); dma_pending = -1; }
     };
 
     // leaving layer jj: count this wave out; the LAST of the workgroup's 8 waves refills the LDS half with layer jj + 2
     auto leave_layer = [&](int jj) {
         int old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&wgctl[1 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) old = __hip_atomic_fetch_add(&wgctl[2 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = __builtin_amdgcn_readfirstlane(old);
         if (old == 7 && jj + 2 < L) {
             if (dma_pending >= 0) flush_owed();       // (a wave that is last twice in a row: announce the earlier refill first)
             // a rolled loop: one running per-lane address (unrolled, the 80 address pairs cost 40 VGPRs at this point)
-            const float* src = p.packed[net] + (size_t)(jj + 2) * p.packed_stride + lane * 4;
+            const float* src = packed_n + (size_t)(jj + 2) * p.packed_stride + lane * 4;
             float* dst = lds + (jj & 1) * kSlot;
 #pragma clang loop unroll(disable)
             for (int c = 0; c < kSlot / 256; ++c)
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     int cur_wa = 0, cur_wb = 0, cur_wneed = 0;      // WAR flags of the task in hand
     Deps curd{};
     if (u >= 0) {
-        if (j >= 2) { flush_owed(); dead = !spin_ge(&wgctl[0], j, p.status, 3, lane); }
+        if (j >= 2) { flush_owed(); dead = !spin_ge(&wgctl[j & 1], j, p.status, 3, lane); }
         curd = deps_of(j, u);
         cur_wa = curd.wa; cur_wb = curd.wb; cur_wneed = curd.war_need;
         war_ok = cur_wneed == 0;
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         {
             int prow = 0;
             if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
-            const float* pr = p.proj[net] + (size_t)prow * p.proj_row_stride + j * 128 + h * 64;
+            const float* pr = proj_n + (size_t)prow * p.proj_row_stride + j * 128 + h * 64;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -311,15 +337,15 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             f_rc = __hip_atomic_load(flags + nxt.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f_wa = __hip_atomic_load(flags + nxt.wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f_wb = __hip_atomic_load(flags + nxt.wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f_ld = __hip_atomic_load(&wgctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f_ld = __hip_atomic_load(&wgctl[j2 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PT_BEGIN();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PT_END(1);
         PT_ADD(6, 1);
         // the previous unit's stores have reached the L2 (and a refill this wave issued has landed): publish
-        if (prev_u >= 0) st_word(flags + prev_u, prev_j + 1, lane);
-        if (dma_pending >= 0) { st_word(&wgctl[0], dma_pending, lane); dma_pending = -1; }
+        if (prev_u >= 0) { st_word(flags + prev_u, prev_j + 1, lane); prev_u = -1; }     // (once: a later re-publish would LOWER a count)
+        if (dma_pending >= 0) { st_word(&wgctl[dma_pending & 1], dma_pending, lane); dma_pending = -1; }
         if (u2 >= 0) claim_v = claim();
         if (need_load) {
             // rows not prefetched (first task, or their producers were not done when the previous iteration looked): wait
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         PT_PHASE(0);      // TOP: loads issued, waited, published
         const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
         const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
-        const float* bdp = p.packed[net] + (size_t)j * p.packed_stride + kBD + h * 32;
+        const float* bdp = packed_n + (size_t)j * p.packed_stride + kBD + h * 32;
 
         f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
         float xc[32];
@@ -444,7 +470,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         PT_END(4);
         prev_u = u; prev_j = j;
         PT_BEGIN();
-        if (u2 >= 0 && j2 != j && !ld_ok2) { flush_owed(); dead = dead || !spin_ge(&wgctl[0], j2, p.status, 3, lane); }
+        if (u2 >= 0 && j2 != j && !ld_ok2) { flush_owed(); dead = dead || !spin_ge(&wgctl[j2 & 1], j2, p.status, 3, lane); }
         PT_END(5);
         i = i2; j = j2; base = base2; u = u2; war_ok = war_ok2;
         cur_wa = nxt.wa; cur_wb = nxt.wb; cur_wneed = nxt.war_need;
@@ -458,15 +484,18 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     if (p.trace && lane == 0) {
         pt_acc[9] = __builtin_amdgcn_s_memtime();
         pt_acc[0] = pt_acc[9] - pt_start;
-        long long* tr = p.trace + ((size_t)(xcc * p.wpx * p.G + slot) * 8 + wave) * 32;
+        long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 32;
         for (int k = 0; k < 10; ++k) tr[16 + k] = pt_ph[k];
         for (int k = 0; k < 10; ++k) tr[k] = pt_acc[k];
         tr[10] = net; tr[11] = xcc; tr[12] = w;
         tr[13] = pt_entry_rt; tr[14] = pt_start_rt; tr[15] = __builtin_amdgcn_s_memrealtime();
+        tr[30] = dead ? 1 : 0; tr[31] = ((long long)j << 32) | (unsigned)u;
+        tr[24] = (long long)flags; tr[25] = (long long)wgctl;
     }
 #endif
     if (prev_u >= 0 && !dead) st_word(flags + prev_u, prev_j + 1, lane);
-    if (dma_pending >= 0) st_word(&wgctl[0], dma_pending, lane);
+    if (dma_pending >= 0) st_word(&wgctl[dma_pending & 1], dma_pending, lane);
+    census();
 }
 
 }  // namespace pwv

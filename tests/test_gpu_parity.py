@@ -253,6 +253,11 @@ def test_logistic_noise(gpu):
     assert np.array_equal(z, z2)                       # counter-based: reproducible
     assert np.isfinite(z).all()
     assert abs(z.mean()) < 0.02 and abs(z.var() - np.pi ** 2 / 3) < 0.1   # Logistic(0,1)
+    # never +-inf: 2^25 consecutive counters hit every 23-bit pattern of u several times, including the extremes
+    # u = 2^-24 and u = 1 - 2^-24 (a 24-bit u rounded to exactly 1.0 once in 2^24 samples: z = +inf, round 2)
+    big = engine.logistic_noise_op((1, 1 << 25, 1), gpu, seed=3)
+    import torch
+    assert bool(torch.isfinite(big).all()) and float(big.abs().max()) <= 16.7
 
 
 @pytest.mark.parametrize('precision', PRECS)

@@ -1,0 +1,116 @@
+"""-m gpu: the persistent dataflow kernel for the residual layers of a stack (csrc/pwv_stack_persist.hip) against the
+per-layer launches -- BIT-identical by construction (same per-unit arithmetic; only the schedule, the buffers and the
+synchronisation differ), on shapes that exercise every protocol path: the production regime (many units per wave), XCDs
+with fewer units than waves (claims span several layers: weight refills and flag publications overlap), one net and two,
+several utterances per batch (x[t-d] = 0 at utterance starts inside an XCD's range), 30-layer stacks (halo of 91 units),
+and the whole model under HIP-graph replay.  Reference loop: modules.py:138-143."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import iaf_oracle as O
+from tests.util import TOL_F32, set_hparams
+
+pytestmark = pytest.mark.gpu
+
+D10 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+
+
+def _nets(gpu, L, G, seed=3):
+    import torch
+    from pwv_amd import engine
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    store = VariableStore(device=gpu, seed=seed)
+    kw = dict(batch_size=1, dilations=(D10 * 3)[:L], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
+              quantization_channels=1, use_biases=True, condition_channels=80, use_skip_connection=False, is_training=False, store=store)
+    nets = [WaveNet(name='n%d' % g, **kw) for g in range(G)]
+    return store, nets
+
+
+@pytest.fixture()
+def persist_knobs():
+    from pwv_amd import engine
+    saved = (engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE)
+    yield engine
+    engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE = saved
+
+
+@pytest.mark.parametrize('n,t,L,G', [(1, 160000, 10, 2), (1, 16000, 10, 2), (1, 8000, 30, 2), (1, 64000, 30, 1), (1, 2400, 6, 2),
+                                     (3, 8000, 10, 2), (5, 1040, 7, 1), (1, 65536, 4, 2)])
+def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G):
+    import torch
+    engine = persist_knobs
+    store, nets = _nets(gpu, L, G)
+    g = torch.Generator().manual_seed(n * 7 + L)
+    x = torch.randn((n, t, 1), generator=g).to(gpu)
+    frames = torch.rand((n, t // 80 + 1, 80), generator=g).to(gpu)
+    cond = engine.RepeatedCondition(frames, 80, 40, t)
+    engine.run_nets(nets, x, cond)                       # creates the variables
+    for name in list(store.vars):
+        if store.vars[name].dim() == 1:
+            store.vars[name].normal_(0, 0.1)
+    store.version += 1
+    engine.PERSIST = False
+    ref = [o.clone() for o in engine.run_nets(nets, x, cond)]
+    engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE = True, 0.0      # force the persistent path whatever the size
+    log = engine.EVENT_LOG = []
+    try:
+        for _ in range(3):
+            got = engine.run_nets(nets, x, cond)
+            torch.cuda.synchronize()
+            assert engine.persist_status() == 0
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b)
+    finally:
+        engine.EVENT_LOG = None
+    assert [e[0] for e in log] == ['persist'] * 3 and log[0][4] == L - 2       # it really was the persistent launch
+
+
+def test_whole_model_persistent_eager_and_graph_replay(gpu, persist_knobs):
+    """The reference-default model (4 flows, 8 nets, 10/10/10/30 layers) at the headline size: per-layer launches,
+    persistent launches and persistent launches replayed from a HIP graph give the same bits; and they match the fp64
+    oracle on a prefix."""
+    import torch
+    from pwv_amd.graph import GraphedVocoder
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    engine = persist_knobs
+    cfg = O.ModelConfig()
+    set_hparams(cfg)
+    w = O.init_weights(cfg, seed=2)
+    store = VariableStore(device=gpu)
+    store.load_dict(w)
+    L = 160000
+    mel, z = O.synthetic_inputs(1, L, cfg)
+    mel_t, z_t = torch.from_numpy(mel).to(gpu), torch.from_numpy(z).to(gpu)
+    model = IAFVocoder(batch_size=1, length=L, store=store)
+    engine.PERSIST = False
+    y0 = model(None, mel_t, is_training=False, z=z_t).clone()
+    engine.PERSIST = True
+    y1 = model(None, mel_t, is_training=False, z=z_t).clone()
+    model.verify()
+    assert torch.equal(y0, y1)
+    graphed = GraphedVocoder(model)
+    for _ in range(3):
+        y2 = graphed(mel_t, z=z_t)
+        model.verify()
+        assert torch.equal(y0, y2)
+    K = 4000
+    want = O.iaf_vocoder_forward(w, mel[:, :K // 80 + 1], z[:, :K], cfg)
+    assert np.abs(y1.cpu().numpy()[:, :K - 40] - want[:, :K - 40]).max() <= TOL_F32
+
+
+def test_persistent_give_up_is_loud_and_falls_back(gpu, persist_knobs):
+    """The kernel reports a give-up (unexpected placement, a poll that ran into its bound) through a sticky word in pinned
+    host memory; the host then raises and uses the per-layer path from then on.  (The word is poked from the host here:
+    a real give-up needs a broken chip.)"""
+    from pwv_amd._lib import PwvError
+    engine = persist_knobs
+    engine.PERSIST = True
+    assert engine.persist_status() == 0
+    ctypes.c_int.from_address(engine._persist_status_addr).value = 4
+    with pytest.raises(PwvError, match='gave up'):
+        engine.raise_if_persist_failed()
+    assert engine.PERSIST is False and engine.persist_status() == 0

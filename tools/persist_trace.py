@@ -29,16 +29,31 @@ def main():
     x = torch.randn((1, rows, 1), generator=g).to(dev)
     frames = torch.rand((1, rows // hop + 1, 80), generator=g).to(dev)
     cond = engine.RepeatedCondition(frames, hop, hop // 2, rows)
-    trace = torch.zeros((256 * 8, 32), dtype=torch.int64, device=dev)
+    trace = torch.zeros((2 * 256 * 8, 32), dtype=torch.int64, device=dev)
     os.environ['PWV_PTRACE_PTR'] = str(trace.data_ptr())
     engine.PERSIST = True
+    engine.PERSIST_UNITS_PER_WAVE = float(os.environ.get('UPW', '2'))
     for _ in range(3):
         engine.run_nets(nets, x, cond)
     torch.cuda.synchronize()
     trace.zero_()
     engine.run_nets(nets, x, cond)
     torch.cuda.synchronize()
-    t = trace.cpu().numpy().astype(np.float64)
+    raw = trace.cpu().numpy()
+    diag = raw[2048:]
+    bad = diag[diag[:, 0] != 0]
+    if len(bad):
+        print('GIVE-UPS: %d waves; by code %s' % (len(bad), {int(c): int((bad[:, 0] == c).sum()) for c in np.unique(bad[:, 0])}))
+        for c in np.unique(bad[:, 0]):
+            b = bad[bad[:, 0] == c]
+            pairs = {}
+            for r in b:
+                pairs[(int(r[1]), int(r[2]))] = pairs.get((int(r[1]), int(r[2])), 0) + 1
+            print('  code %d: (need, value) -> count: %s' % (c, sorted(pairs.items())[:12]))
+        st = raw[:2048]
+        st = st[(st[:, 6] > 0) | (st[:, 30] != 0)]
+        print('  final (layer, unit) of dead waves: %s' % sorted(set((int(r[31] >> 32), int(r[31] & 0xffffffff)) for r in st if r[30]))[:40])
+    t = raw[:2048].astype(np.float64)
     t = t[t[:, 6] > 0]
     names = ['loop total', 'TOP wait vmcnt(0)', 'RAW spins', 'WAR spins', 'leave_layer', 'weight-ready spins']
     print('%d waves, units per wave: mean %.1f (min %d, max %d); status %d' % (len(t), t[:, 6].mean(), t[:, 6].min(), t[:, 6].max(), engine.persist_status()))
