@@ -268,9 +268,17 @@ def main():
             from pwv_amd.graph import GraphedVocoder
             try:
                 graphed = GraphedVocoder(model)
+                # self-check (untimed): a replay must reproduce the host-enqueued forward bit for bit on the same noise
+                zc = engine.logistic_noise_op((utts, length, 1), dev, seed=12345)
+                want = model(None, mel, is_training=False, z=zc).clone()
+                got = graphed(mel, z=zc)
+                torch.cuda.synchronize()
+                if not torch.equal(want, got):
+                    raise RuntimeError('HIP-graph replay differs from the host-enqueued forward')
+                del want, got, zc
                 return (lambda: graphed(mel)), eager_step, True
             except Exception as e:      # never lose the measurement to a capture problem: same launches, host-enqueued
-                sys.stderr.write('graph capture failed (%s: %s); falling back to host-enqueued launches\n' % (type(e).__name__, e))
+                sys.stderr.write('graph capture / replay check failed (%s: %s); falling back to host-enqueued launches\n' % (type(e).__name__, e))
                 torch.cuda.synchronize()
                 return eager_step, eager_step, False
 

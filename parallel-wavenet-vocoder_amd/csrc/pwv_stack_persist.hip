@@ -498,6 +498,14 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     census();
 }
 
+// every polled word starts at zero on EVERY call.  A kernel, not hipMemsetAsync: under stream capture the memset node of a
+// torch-captured graph did not reset the words on replay (the replays then found every flag already satisfied and every
+// task already claimed -- fast and wrong; tests/test_gpu_persist.py::test_whole_model_persistent_eager_and_graph_replay)
+__global__ void persist_zero_kernel(int4* p, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = int4{0, 0, 0, 0};
+}
+
 }  // namespace pwv
 
 using namespace pwv;
@@ -590,8 +598,8 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }
 #endif
     hipStream_t s = (hipStream_t)stream;
-    // every polled word starts at zero on EVERY call (a memset node when captured into a graph)
-    PWV_CHECK_HIP(hipMemsetAsync(ws, 0, ctl_bytes, s));
+    const size_t n16 = ctl_bytes / 16;
+    hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)ws, n16);
     hipLaunchKernelGGL(stack_persist_kernel, dim3(cus), dim3(512), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "persistent stack kernel launch failed: %s", hipGetErrorString(e));

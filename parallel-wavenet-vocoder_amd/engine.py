@@ -49,11 +49,12 @@ TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
 FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
 # PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
 FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
-# PWV_PERSIST=0: always one launch per layer.  Default: the residual layers 1 .. L-2 of a stack run as ONE persistent
-# dataflow launch (csrc/pwv_stack_persist.hip) whenever the input is large enough for it (bit-identical results).
-PERSIST = os.environ.get('PWV_PERSIST', '1') != '0'
-# units per XCD (and net) the persistent launch wants per wave sharing them.  Below ~2 the per-layer launches are as fast
-# (and claims start to span layers); tests set 0 to force the persistent path onto small inputs.
+# PWV_PERSIST=1: run the residual layers 1 .. L-2 of a stack as ONE persistent dataflow launch (csrc/pwv_stack_persist.hip,
+# bit-identical results) instead of one launch per layer.  OFF by default: measured under HIP-graph replay on MI355X it is
+# at parity with the two-stream per-layer launches at every size tried (C3 3.12 vs 3.07 ms per step, C4 9.81 vs 9.40 ms,
+# 1 s inputs 1.17 vs 0.94 ms) -- the per-unit issue time of the MFMA + VALU stream bounds both.
+PERSIST = os.environ.get('PWV_PERSIST', '0') != '0'
+# units per XCD (and net) the persistent launch wants per wave sharing them; tests set 0 to force it onto small inputs
 PERSIST_UNITS_PER_WAVE = float(os.environ.get('PWV_PERSIST_UNITS_PER_WAVE', '2'))
 _persist_status_addr = None
 _side_streams = {}
