@@ -309,6 +309,26 @@ typedef struct pwv_stack_args {
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);
 
 /* ---------------------------------------------------------------------------------------
+ * Normalisers (modules.normalize, modules.py:263-284) and the elementwise ops of the un-fused WaveNet path.
+ *   pwv_instance_norm_f32   method 'in' (modules.py:274-284): per (utterance, channel) mean / biased variance over the
+ *                           TIME axis, y = gamma (x - mean) / sqrt(var + eps) + beta, eps = 1e-8 in the reference;
+ *                           x, y [N, T, C] channels-last; gamma / beta [C] or NULL; two launches (fp64 partial sums per
+ *                           time chunk, no atomics: bitwise repeatable), workspace from pwv_instance_norm_workspace_bytes.
+ *   pwv_channel_affine_f32  y = act(x * scale[c] + bias[c]) -- method 'bn' at inference (modules.py:266: scale =
+ *                           gamma / sqrt(moving_variance + 1e-3), bias = beta - moving_mean * scale) where no GEMM follows
+ *                           that the host could fold it into; also bias adds and relu.  scale / bias may be NULL;
+ *                           tile32 != 0: x, y are tile32 buffers (C % 4 == 0); in place (x == y) allowed.
+ *   pwv_add_f32, pwv_gate_f32   out = a + b;  out = tanh(f) * sigmoid(g) (modules.py:236).
+ * ------------------------------------------------------------------------------------- */
+size_t pwv_instance_norm_workspace_bytes(int N, int T, int C);
+int pwv_instance_norm_f32(const float* x, float* y, int N, int T, int C, const float* gamma, const float* beta, float eps,
+                          void* workspace, size_t workspace_bytes, pwv_stream_t stream);
+int pwv_channel_affine_f32(const float* x, float* y, int64_t rows, int C, const float* scale, const float* bias, int tile32,
+                           int relu, pwv_stream_t stream);
+int pwv_add_f32(const float* a, const float* b, float* out, int64_t n, pwv_stream_t stream);
+int pwv_gate_f32(const float* f, const float* g, float* out, int64_t n, pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation, no per-sample condition,
  * PWV_PREC_F16X3) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
  * (modules.py:138-143) without a kernel boundary, a weight-staging phase and a ramp-up / ramp-down per layer.

@@ -384,7 +384,8 @@ def iaf_vocoder_forward(weights: Weights, mel: np.ndarray, z: np.ndarray, cfg: M
     else:
         cond = None                                                         # models.py:134-135
     if cond is not None and cfg.normalize_cond:                             # models.py:27-29
-        cond = normalize(cond, cfg.normalize_cond, weights, 'iaf_vocoder/cond/normalize')
+        # models.py:27-29: tf.variable_scope('normalize') around normalize(), whose own default scope is 'normalize' again
+        cond = normalize(cond, cfg.normalize_cond, weights, 'iaf_vocoder/cond/normalize/normalize')
     x = z.astype(dtype)
     flows = []
     for i in range(cfg.n_iaf):                                              # models.py:34-70

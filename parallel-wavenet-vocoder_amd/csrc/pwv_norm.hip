@@ -1,0 +1,190 @@
+// Normalisers and the small elementwise ops of the un-fused WaveNet path, gfx950.
+//   instance_normalization                       /root/reference/modules.py:274-284  (moments over the TIME axis, eps 1e-8)
+//   batch_normalization at inference             /root/reference/modules.py:266      (a per-channel affine; the host folds it
+//                                                 into the packed weights wherever a GEMM follows -- this file only has the
+//                                                 affine for the places where no GEMM does)
+//   tanh(filter) * sigmoid(gate), adds, relu     /root/reference/modules.py:236,148,157,251
+// All HBM-bound elementwise / reduction kernels over channels-last [rows, C] tensors (and tile32 buffers for the affine).
+#include "pwv_common.h"
+
+namespace pwv {
+
+// y[r, c] = act(x[r, c] * scale[c] + bias[c]); scale / bias may be NULL (1 / 0).  tile32: the buffer is in the fused
+// kernels' 32-row tiled layout (index -> channel = ((i / 128) % (C/4)) * 4 + i % 4).
+__global__ void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int C,
+                                      const float* __restrict__ scale, const float* __restrict__ bias, int tile32, int relu) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4
+    if (i >= total4) return;
+    const int c4 = C / 4;
+    const int c = tile32 ? (int)((i / 32) % c4) * 4 : (int)(i % c4) * 4;
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = v[e];
+        if (scale) t *= scale[c + e];
+        if (bias) t += bias[c + e];
+        v[e] = relu ? fmaxf(t, 0.f) : t;
+    }
+    reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
+// scalar-channel variant (C not a multiple of 4, e.g. the [N, T, 1] flow output)
+__global__ void channel_affine1_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int C,
+                                       const float* __restrict__ scale, const float* __restrict__ bias, int relu) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float t = x[i];
+    if (scale) t *= scale[c];
+    if (bias) t += bias[c];
+    y[i] = relu ? fmaxf(t, 0.f) : t;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+// out = tanh(f) * sigmoid(g)  (modules.py:236), libm-accurate forms: this is the reference-shaped slow path
+__global__ void gate_kernel(const float* __restrict__ f, const float* __restrict__ g, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = tanhf(f[i]) * (1.f / (1.f + expf(-g[i])));
+}
+
+// ---- instance normalisation: per (utterance, channel) moments over time ----------------------------------------------
+// Pass 1: block (chunk, n) sums x and x^2 of its time chunk for every channel in fp64 (the one-pass E[x^2] - E[x]^2 form
+// is safe there) and writes them to partial[n][chunk][c][2] -- no atomics, so the result is bitwise repeatable.
+// Pass 2: every block first reduces the partials of its channels (<= kInMaxChunks), then normalises its rows.
+constexpr int kInMaxChunks = 512;
+
+__global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int T, int C, int chunk_len,
+                                                       int chunks) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int t0 = ch * chunk_len, t1 = (t0 + chunk_len < T) ? t0 + chunk_len : T;
+    // thread = (time lane, channel lane): consecutive threads read consecutive channels (coalesced along C)
+    const int cl = C < 256 ? C : 256;              // channels handled per sweep
+    const int tl = 256 / cl > 0 ? 256 / cl : 1;    // time lanes
+    const int tc = threadIdx.x % cl, tt = threadIdx.x / cl;
+    for (int c0 = 0; c0 < C; c0 += cl) {
+        const int c = c0 + tc;
+        double s = 0.0, q = 0.0;
+        if (c < C && tt < tl)
+            for (int t = t0 + tt; t < t1; t += tl) {
+                const double v = (double)x[((size_t)n * T + t) * C + c];
+                s += v;
+                q += v * v;
+            }
+        red[0][threadIdx.x] = s;
+        red[1][threadIdx.x] = q;
+        __syncthreads();
+        if (tt == 0 && c < C) {
+            for (int k = 1; k < tl; ++k) { s += red[0][k * cl + tc]; q += red[1][k * cl + tc]; }
+            double* dst = partial + (((size_t)n * chunks + ch) * C + c) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const double* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int T, int C,
+                                                       int chunks, int rows_per_block, float eps) {
+    extern __shared__ float ab[];      // [C] scale, [C] shift
+    const int n = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const double* src = partial + (((size_t)n * chunks + k) * C + c) * 2;
+            s += src[0];
+            q += src[1];
+        }
+        const double mean = s / T;
+        double var = q / T - mean * mean;               // tf.nn.moments: the biased variance
+        if (var < 0.0) var = 0.0;
+        const double inv = 1.0 / sqrt(var + (double)eps);     // (variance + epsilon) ** .5, modules.py:282
+        const double gm = gamma ? (double)gamma[c] : 1.0;
+        ab[c] = (float)(gm * inv);
+        ab[C + c] = (float)((beta ? (double)beta[c] : 0.0) - gm * inv * mean);
+    }
+    __syncthreads();
+    const int t0 = blockIdx.x * rows_per_block;
+    const int t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+    const size_t base = ((size_t)n * T + t0) * C;
+    const size_t total = (size_t)(t1 - t0) * C;
+    for (size_t i = threadIdx.x; i < total; i += 256) {
+        const int c = (int)((base + i) % C);
+        y[base + i] = fmaf(x[base + i], ab[c], ab[C + c]);
+    }
+}
+
+static inline unsigned nblocks(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
+
+}  // namespace pwv
+
+using namespace pwv;
+
+extern "C" {
+
+int pwv_channel_affine_f32(const float* x, float* y, int64_t rows, int C, const float* scale, const float* bias, int tile32, int relu,
+                           pwv_stream_t stream) {
+    PWV_CHECK_ARG(x && y && rows >= 0 && C >= 1, "pwv_channel_affine_f32: bad arguments");
+    PWV_CHECK_ARG(!tile32 || C % 4 == 0, "pwv_channel_affine_f32: a tile32 buffer has a multiple of 4 channels");
+    if (rows == 0) return PWV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (C % 4 == 0) {
+        const long long total4 = (tile32 ? (rows + 31) / 32 * 32 : rows) * (C / 4);
+        hipLaunchKernelGGL(channel_affine_kernel, dim3(nblocks(total4, 256)), dim3(256), 0, s, x, y, total4, C, scale, bias, tile32, relu);
+    } else {
+        const long long total = rows * C;
+        hipLaunchKernelGGL(channel_affine1_kernel, dim3(nblocks(total, 256)), dim3(256), 0, s, x, y, total, C, scale, bias, relu);
+    }
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_add_f32(const float* a, const float* b, float* out, int64_t n, pwv_stream_t stream) {
+    PWV_CHECK_ARG(a && b && out && n >= 0 && n % 4 == 0, "pwv_add_f32: bad arguments (n must be a multiple of 4)");
+    if (n == 0) return PWV_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(nblocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)(n / 4));
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_gate_f32(const float* f, const float* g, float* out, int64_t n, pwv_stream_t stream) {
+    PWV_CHECK_ARG(f && g && out && n >= 0, "pwv_gate_f32: bad arguments");
+    if (n == 0) return PWV_OK;
+    hipLaunchKernelGGL(gate_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, f, g, out, (long long)n);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+size_t pwv_instance_norm_workspace_bytes(int N, int T, int C) {
+    if (N < 1 || T < 1 || C < 1) return 0;
+    int chunks = (T + 2047) / 2048;
+    if (chunks > kInMaxChunks) chunks = kInMaxChunks;
+    return (size_t)N * chunks * C * 2 * sizeof(double);
+}
+
+int pwv_instance_norm_f32(const float* x, float* y, int N, int T, int C, const float* gamma, const float* beta, float eps,
+                          void* workspace, size_t workspace_bytes, pwv_stream_t stream) {
+    PWV_CHECK_ARG(x && y && workspace, "pwv_instance_norm_f32: NULL pointer");
+    PWV_CHECK_ARG(N >= 1 && T >= 1 && C >= 1 && C <= 4096, "pwv_instance_norm_f32: bad shape N=%d T=%d C=%d", N, T, C);
+    PWV_CHECK_ARG(workspace_bytes >= pwv_instance_norm_workspace_bytes(N, T, C), "pwv_instance_norm_f32: workspace too small");
+    int chunks = (T + 2047) / 2048;
+    if (chunks > kInMaxChunks) chunks = kInMaxChunks;
+    const int chunk_len = (T + chunks - 1) / chunks;
+    chunks = (T + chunk_len - 1) / chunk_len;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(in_stats_kernel, dim3(chunks, N), dim3(256), 0, s, x, (double*)workspace, T, C, chunk_len, chunks);
+    const int rows_per_block = 256;
+    hipLaunchKernelGGL(in_apply_kernel, dim3((T + rows_per_block - 1) / rows_per_block, N), dim3(256), 2 * C * sizeof(float), s, x, y,
+                       (const double*)workspace, gamma, beta, T, C, chunks, rows_per_block, eps);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+}  // extern "C"

@@ -226,6 +226,58 @@ def logistic_noise_op(shape: Sequence[int], device, seed: int, offset: int = 0, 
     return z
 
 
+def instance_norm_op(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-8) -> torch.Tensor:
+    """modules.instance_normalization (modules.py:274-284) on a channels-last [N, T, C] tensor."""
+    x = _require_cuda_f32(x, 'input')
+    n, t, c = x.shape
+    y = torch.empty_like(x)
+    if x.numel() == 0:
+        return y
+    lib = _lib.lib()
+    nbytes = lib.pwv_instance_norm_workspace_bytes(n, t, c)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    check(lib.pwv_instance_norm_f32(_ptr(x), _ptr(y), n, t, c, _ptr(gamma), _ptr(beta), float(eps), ws.data_ptr(), nbytes, _stream()),
+          'pwv_instance_norm_f32')
+    return y
+
+
+def channel_affine_op(x: torch.Tensor, scale: Optional[torch.Tensor], bias: Optional[torch.Tensor], relu: bool = False,
+                      tile32_rows: int = 0, channels: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(x * scale[c] + bias[c]) over the last axis (or over a tile32 buffer of `tile32_rows` x `channels`)."""
+    y = out if out is not None else torch.empty_like(x)
+    if x.numel() == 0:
+        return y
+    if tile32_rows:
+        rows, c, tiled = tile32_rows, channels, 1
+    else:
+        c = x.shape[-1]
+        rows, tiled = x.numel() // c, 0
+    check(_lib.lib().pwv_channel_affine_f32(_ptr(x), _ptr(y), rows, c, _ptr(scale), _ptr(bias), tiled, int(relu), _stream()),
+          'pwv_channel_affine_f32')
+    return y
+
+
+def add_op(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    if a.numel() % 4 == 0:
+        check(_lib.lib().pwv_add_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), 'pwv_add_f32')
+        return out
+    # odd sizes (scalar-channel tensors): the affine kernel's scalar path with a per-element "bias" is not available;
+    # pad-free fallback through two launches on the multiple-of-4 prefix and the tail
+    n4 = a.numel() // 4 * 4
+    af, bf, of = a.reshape(-1), b.reshape(-1), out.reshape(-1)
+    if n4:
+        check(_lib.lib().pwv_add_f32(_ptr(af), _ptr(bf), _ptr(of), n4, _stream()), 'pwv_add_f32')
+    of[n4:] = af[n4:] + bf[n4:]
+    return out
+
+
+def gate_op(f: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(f)
+    check(_lib.lib().pwv_gate_f32(_ptr(f), _ptr(g), _ptr(out), f.numel(), _stream()), 'pwv_gate_f32')
+    return out
+
+
 def iaf_affine_op(z: torch.Tensor, s: torch.Tensor, b: torch.Tensor, sb_stride: int = 1) -> torch.Tensor:
     """out = z*s + b (modules.py:59); s/b may be strided views (shared net: stride 2)."""
     n, t = z.shape[0], z.shape[1]
@@ -257,9 +309,13 @@ class NetPlan:
         # (csrc/pwv_layer_common.h: kFScale / kGScale; the packed filter/gate weights carry them too)
         fg_scale = torch.cat([torch.full((64,), -2.8853900817779268), torch.full((64,), -1.4426950408889634)]).to(
             device=dev, dtype=torch.float32)
+        # normalize='bn' (inference): every batch norm of the net is folded into these tensors (WaveNet.folded_variables)
+        folded = net.folded_variables(cond_mode != 'none') if net.normalize == 'bn' else None
+        self._lv = (lambda j: folded['layers'][j]) if folded else (lambda j: net.layer_variables(j, with_cond=cond_mode != 'none'))
+        self._hv = folded['head'] if folded else net.head_variables()
         proj_w, proj_b = [], []
         for j in range(L):
-            v = net.layer_variables(j, with_cond=cond_mode != 'none')
+            v = self._lv(j)
             check(lib.pwv_pack_layer_f32(_ptr(v['filter']), _ptr(v['gate']), _ptr(v['dense']), _ptr(v.get('dense_bias')),
                                          _ptr(v['skip']) if use_skip else None,
                                          _ptr(v.get('skip_bias')) if use_skip else None,
@@ -267,7 +323,7 @@ class NetPlan:
                                          _ptr(v.get('gc_gate')) if cond_c else None,
                                          int(use_skip), cond_c, precision, _ptr(self.packed_layers[j]), s),
                   'pwv_pack_layer_f32')
-            if net.use_biases:
+            if 'filter_bias' in v:
                 b = torch.cat([v['filter_bias'], v['gate_bias']])
             else:
                 b = torch.zeros(128, dtype=torch.float32, device=dev)
@@ -277,8 +333,8 @@ class NetPlan:
                 proj_w.append((wfg * fg_scale)[:, colmap])
         self.proj_b = torch.cat(proj_b).contiguous()                              # [128*L]
         self.proj_w = torch.cat(proj_w, dim=1).contiguous() if proj_w else None   # [C, 128*L]
-        hv = net.head_variables()
-        last = net.layer_variables(L - 1, with_cond=False)
+        hv = self._hv
+        last = self._lv(L - 1)
         self.head_floats = lib.pwv_head_packed_floats(net.out_channels)
         self.packed_head = torch.empty((self.head_floats,), dtype=torch.float32, device=dev)
         check(lib.pwv_pack_head_f32(None if use_skip else _ptr(last['skip']),
@@ -286,7 +342,9 @@ class NetPlan:
                                     _ptr(hv['postprocess1']), _ptr(hv.get('postprocess1_bias')),
                                     _ptr(hv['postprocess2']), _ptr(hv.get('postprocess2_bias')),
                                     net.out_channels, precision, _ptr(self.packed_head), s), 'pwv_pack_head_f32')
-        self.causal_filter = net.causal_filter()
+        self.causal_bias = folded['causal_bias'] if folded else None      # batch norm behind the causal layer: its shift
+        self._causal_filter_folded = folded['causal_filter'].contiguous() if folded else None
+        self.causal_filter = self._causal_filter_folded if self._causal_filter_folded is not None else net.causal_filter()
         self.n_layers = L
         self.f16x3_ok, self.x_limit = True, 3.0e38
         if precision == _lib.PREC_F16X3:
@@ -299,7 +357,7 @@ class NetPlan:
         kf, kg = 2.8853900817779268, 1.4426950408889634
         wmax, c_res, skip_terms = [], [], []
         for j in range(L):
-            v = net.layer_variables(j, with_cond=cond_mode != 'none')
+            v = self._lv(j)
             wmax += [v['filter'].abs().max() * kf, v['gate'].abs().max() * kg, v['dense'].abs().max(), v['skip'].abs().max()]
             if cond_mode != 'none':
                 wmax += [v['gc_filter'].abs().max() * kf, v['gc_gate'].abs().max() * kg]
@@ -309,7 +367,7 @@ class NetPlan:
             if use_skip or j == L - 1:
                 c = v['skip'][0].abs().sum(dim=0).max()
                 skip_terms.append(c + v['skip_bias'].abs().max() if 'skip_bias' in v else c)
-        hv = net.head_variables()
+        hv = self._hv
         wmax.append(hv['postprocess1'].abs().max())
         zero = torch.zeros((), device=self.causal_filter.device)
         stats = torch.stack([torch.stack(wmax).max(), torch.stack(c_res).sum() if c_res else zero, torch.stack(skip_terms).sum(),
@@ -328,7 +386,8 @@ def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
     # use_skip_connection toggled (no variable is created then, so the store version alone does not change)
     key = (net.store.uid, net.full_scope, cond_mode, precision, tuple(int(d) for d in net.dilations),
            bool(net.use_skip_connection), bool(net.use_biases), net.in_channels, net.out_channels,
-           net.condition_channels, net.filter_width, net.residual_channels, net.dilation_channels, net.skip_channels)
+           net.condition_channels, net.filter_width, net.residual_channels, net.dilation_channels, net.skip_channels,
+           net.normalize or '')
     hit = _plan_cache.get(key)
     if hit is not None and hit[0] == net.store.version:
         return hit[1]
@@ -527,7 +586,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # split-fp16 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself (pwv_layer_args.x_first),
     # so the [rows, 64] front buffer is neither written nor read
     first_fused = (FUSE_FIRST and prec == _lib.PREC_F16X3 and qin == 1 and net0.filter_width == 2 and R == 64
-                   and not net0.use_skip_connection)
+                   and not net0.use_skip_connection and plans[0].causal_bias is None)
     if prec == _lib.PREC_F16X3 and not first_fused:
         range_check_op(x, x_limit)          # (layer 0 checks its scalar input itself when it rebuilds the causal layer)
     if first_fused:
@@ -537,6 +596,11 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
         hout = (c_void_p * G)(*[b[0].data_ptr() for b in bufs])
         front = lib.pwv_iaf_front_f16 if half else lib.pwv_iaf_front_f32
         check(front(_ptr(x), None, None, 1, None, G, filt, hout, n, t, net0.filter_width, R, s), 'pwv_iaf_front')
+        for g, p in enumerate(plans):
+            if p.causal_bias is not None:      # normalize='bn': the shift of the batch norm behind the causal layer (modules.py:182)
+                if half:
+                    raise _lib.PwvError("precision 'f16' does not support normalize='bn'")
+                channel_affine_op(bufs[g][0], None, p.causal_bias, tile32_rows=rows, channels=R, out=bufs[g][0])
     else:
         for g, p in enumerate(plans):      # multi-channel input: generic causal conv, then into tile32
             hrows = torch.empty((n, t, R), dtype=torch.float32, device=dev)

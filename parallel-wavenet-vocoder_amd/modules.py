@@ -26,32 +26,44 @@ def causal_conv(value, filter_, dilation, name='causal_conv'):
     return engine.causal_conv_op(value, filter_, int(dilation))
 
 
+BN_EPS = 1e-3        # tf.layers.batch_normalization default epsilon (modules.py:266)
+IN_EPS = 1e-8        # instance_normalization(epsilon=1e-8), modules.py:274
+
+
+def bn_inference_affine(store: VariableStore, prefix: str, c: int):
+    """tf.layers.batch_normalization(training=False) as y = x * a + b with a = gamma / sqrt(moving_variance + eps),
+    b = beta - moving_mean * a (variables under `<prefix>/batch_normalization/`, TF's names)."""
+    p = prefix + '/batch_normalization/'
+    gamma = store.get_variable(p + 'gamma', [c], 'ones')
+    beta = store.get_variable(p + 'beta', [c], 'zeros')
+    mean = store.get_variable(p + 'moving_mean', [c], 'zeros')
+    var = store.get_variable(p + 'moving_variance', [c], 'ones')
+    a = gamma / torch.sqrt(var + BN_EPS)
+    return a, beta - mean * a
+
+
 def normalize(input, is_training, method='bn', name='normalize', store: Optional[VariableStore] = None):
     """modules.py:263-270.  Identity unless method is 'bn' / 'in' (the default hparams use '').
-    'bn' at inference is a per-channel affine of the moving statistics; 'in' normalises over
-    the time axis (modules.py:274-284).  These two are "next" rows: they run
-    as torch device ops, not in the fused kernels."""
+    'bn' at inference is a per-channel affine of the moving statistics (pwv_channel_affine_f32; inside a fused WaveNet it
+    is folded into the packed weights instead, WaveNet.folded_variables); 'in' normalises over the time axis
+    (modules.py:274-284, pwv_instance_norm_f32)."""
     if method not in ('bn', 'in'):
         return input
     store = store or get_default_store()
-    with variable_scope(name):
-        c = input.shape[-1]
-        if method == 'bn':
-            if is_training:
-                raise NotImplementedError('batch-norm training statistics are out of scope (generation path only)')
-            with variable_scope('batch_normalization'):
-                from .variables import get_variable
-                gamma = get_variable('gamma', [c], 'ones', store)
-                beta = get_variable('beta', [c], 'zeros', store)
-                mean = get_variable('moving_mean', [c], 'zeros', store)
-                var = get_variable('moving_variance', [c], 'ones', store)
-            return (input - mean) / torch.sqrt(var + 1e-3) * gamma + beta
-        from .variables import get_variable
-        beta = get_variable('beta', [c], 'zeros', store)
-        gamma = get_variable('gamma', [c], 'ones', store)
-        mean = input.mean(dim=1, keepdim=True)
-        var = ((input - mean) ** 2).mean(dim=1, keepdim=True)
-        return gamma * (input - mean) / torch.sqrt(var + 1e-8) + beta
+    from .variables import scoped
+    prefix = scoped(name)
+    c = input.shape[-1]
+    if method == 'bn':
+        if is_training:
+            raise NotImplementedError('batch-norm training statistics are out of scope (generation path only)')
+        a, b = bn_inference_affine(store, prefix, c)
+        return engine.channel_affine_op(engine._require_cuda_f32(input, 'input'), a, b)
+    beta = store.get_variable(prefix + '/beta', [c], 'zeros')
+    gamma = store.get_variable(prefix + '/gamma', [c], 'ones')
+    x = engine._require_cuda_f32(input, 'input')
+    squeeze = x.dim() == 2
+    y = engine.instance_norm_op(x.unsqueeze(0) if squeeze else x, gamma, beta, IN_EPS)
+    return y[0] if squeeze else y
 
 
 class WaveNet(object):
@@ -137,12 +149,76 @@ class WaveNet(object):
             v['postprocess2_bias'] = self._var(p + 'postprocess2_bias', [Q], 'zeros')
         return v
 
+    # -- batch norm at inference folded into the weights -------------------------------------
+    def _bn(self, rel, c):
+        return bn_inference_affine(self.store, self.full_scope + '/' + rel, c)
+
+    def _residual_scales(self):
+        """S_j: the per-channel factor between the residual stream x_j the reference computes and the stream y_j the fused
+        kernels carry (x_j = S_j * y_j): the batch norm of a layer's dense output scales the IDENTITY branch too
+        (x_{j+1} = a (x_j + o W + b) + c, modules.py:251-257), which the fused layer cannot express -- but a diagonal scale
+        of the stream can be moved into the next layer's filter rows and out of this layer's dense columns."""
+        R = self.residual_channels
+        S = [torch.ones(R, dtype=torch.float32, device=self.device())]
+        for j in range(len(self.dilations) - 1):
+            a, _ = self._bn('dilated_stack/layer%d/normalize_dense_output' % j, R)
+            S.append(S[-1] * a)
+        return S
+
+    def _bn_foldable(self) -> bool:
+        key = (self.store.uid, self.store.version)
+        if getattr(self, '_bn_ok_key', None) != key:
+            S = torch.stack(self._residual_scales()).abs()
+            self._bn_ok_key, self._bn_ok = key, bool(((S > 1e-4) & (S < 1e4)).all().item())
+        return self._bn_ok
+
+    def folded_variables(self, with_cond: bool):
+        """The weights a batch-norm-free net of the same architecture needs to compute what this net with
+        normalize='bn' (inference) computes: every normaliser of modules.py:150-160,182,230-234,253-257 is a per-channel
+        affine next to a convolution.  Returns {'causal_filter', 'causal_bias', 'layers': [...], 'head': {...}} in TF layouts."""
+        R, D, S_, Q = self.residual_channels, self.dilation_channels, self.skip_channels, self.out_channels
+        L = len(self.dilations)
+        a0, c0 = self._bn('causal_layer/normalize', R)
+        out = {'causal_filter': self.causal_filter() * a0, 'causal_bias': c0.contiguous(), 'layers': []}
+        S = self._residual_scales()
+        zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device())
+        for j in range(L):
+            v = self.layer_variables(j, with_cond)
+            p = 'dilated_stack/layer%d/' % j
+            aF, cF = self._bn(p + 'normalize_filter', D)
+            aG, cG = self._bn(p + 'normalize_gate', D)
+            aS, cS = self._bn(p + 'normalize_skip_output', S_)
+            w = {'filter': (v['filter'] * S[j][None, :, None] * aF).contiguous(), 'gate': (v['gate'] * S[j][None, :, None] * aG).contiguous(),
+                 'filter_bias': (v.get('filter_bias', zeros(D)) * aF + cF).contiguous(),
+                 'gate_bias': (v.get('gate_bias', zeros(D)) * aG + cG).contiguous(),
+                 'skip': (v['skip'] * aS).contiguous(), 'skip_bias': (v.get('skip_bias', zeros(S_)) * aS + cS).contiguous()}
+            if with_cond:
+                w['gc_filter'] = (v['gc_filter'] * aF).contiguous()
+                w['gc_gate'] = (v['gc_gate'] * aG).contiguous()
+            if j < L - 1:
+                _, cD = self._bn(p + 'normalize_dense_output', R)
+                w['dense'] = (v['dense'] / S[j]).contiguous()
+                w['dense_bias'] = (v.get('dense_bias', zeros(R)) / S[j] + cD / S[j + 1]).contiguous()
+            else:       # the last layer's dense output is not used (modules.py:147: only its skip output is)
+                w['dense'] = v['dense']
+                w['dense_bias'] = v.get('dense_bias', zeros(R))
+            out['layers'].append(w)
+        hv = self.head_variables()
+        a1, c1 = self._bn('postprocessing/normalize_postprocess1', S_)
+        a2, c2 = self._bn('postprocessing/normalize_postprocess2', S_)
+        out['head'] = {'postprocess1': (hv['postprocess1'] * a1[None, :, None]).contiguous(),
+                       'postprocess1_bias': (hv.get('postprocess1_bias', zeros(S_)) + c1 @ hv['postprocess1'][0]).contiguous(),
+                       'postprocess2': (hv['postprocess2'] * a2[None, :, None]).contiguous(),
+                       'postprocess2_bias': (hv.get('postprocess2_bias', zeros(Q)) + c2 @ hv['postprocess2'][0]).contiguous()}
+        return out
+
     def fused_supported(self, condition) -> bool:
         """The fused HIP layer/head kernels cover the default architecture
         (hparams/default.yaml:22-26): W=2, R=D=64, S=128, no normalisers."""
         ok = (self.filter_width == 2 and self.residual_channels == 64 and self.dilation_channels == 64
-              and self.skip_channels == 128 and not self.normalize and 1 <= self.out_channels <= 4
-              and len(self.dilations) >= 1)
+              and self.skip_channels == 128 and 1 <= self.out_channels <= 4 and len(self.dilations) >= 1
+              and (not self.normalize or (self.normalize == 'bn' and not self.is_training and self.in_channels == 1
+                                          and self._bn_foldable())))
         if condition is None:
             return ok
         if isinstance(condition, RepeatedCondition):
@@ -165,6 +241,7 @@ class WaveNet(object):
         x = engine._require_cuda_f32(input_batch, 'input_batch')
         cond = None if condition_batch is None else engine._require_cuda_f32(condition_batch, 'condition_batch')
         cc = engine.causal_conv_op
+        add, bias_add = engine.add_op, lambda t, b: engine.channel_affine_op(t, None, b)
         scope = self.full_scope
         cur = cc(x, self.causal_filter(), 1)
         if self.normalize:
@@ -176,23 +253,23 @@ class WaveNet(object):
             f = cc(cur, v['filter'], d)
             g = cc(cur, v['gate'], d)
             if cond is not None:
-                f = f + cc(cond, v['gc_filter'], 1)
-                g = g + cc(cond, v['gc_gate'], 1)
+                f = add(f, cc(cond, v['gc_filter'], 1))
+                g = add(g, cc(cond, v['gc_gate'], 1))
             if self.use_biases:
-                f = f + v['filter_bias']
-                g = g + v['gate_bias']
+                f = bias_add(f, v['filter_bias'])
+                g = bias_add(g, v['gate_bias'])
             lscope = scope + '/dilated_stack/layer%d' % j
             if self.normalize:
                 with variable_scope(lscope, absolute=True):
                     f = normalize(f, self.is_training, self.normalize, 'normalize_filter', self.store)
                     g = normalize(g, self.is_training, self.normalize, 'normalize_gate', self.store)
-            out = torch.tanh(f) * torch.sigmoid(g)
+            out = engine.gate_op(f, g)                                   # tanh(f) * sigmoid(g), modules.py:236
             transformed = cc(out, v['dense'], 1)
             skip = cc(out, v['skip'], 1)
             if self.use_biases:
-                transformed = transformed + v['dense_bias']
-                skip = skip + v['skip_bias']
-            dense_out = cur + transformed
+                transformed = bias_add(transformed, v['dense_bias'])
+                skip = bias_add(skip, v['skip_bias'])
+            dense_out = add(cur, transformed)
             if self.normalize:
                 with variable_scope(lscope, absolute=True):
                     skip = normalize(skip, self.is_training, self.normalize, 'normalize_skip_output', self.store)
@@ -200,22 +277,25 @@ class WaveNet(object):
             outputs.append(skip)
             cur = dense_out
         hv = self.head_variables()
-        total = sum(outputs) if self.use_skip_connection else outputs[-1]
-        t1 = torch.relu(total)
+        if self.use_skip_connection:
+            total = outputs[0]
+            for o in outputs[1:]:
+                total = add(total, o)
+        else:
+            total = outputs[-1]
+        t1 = engine.channel_affine_op(total, None, None, relu=True)
         pscope = scope + '/postprocessing'
         if self.normalize:
             with variable_scope(pscope, absolute=True):
                 t1 = normalize(t1, self.is_training, self.normalize, 'normalize_postprocess1', self.store)
         c1 = cc(t1, hv['postprocess1'], 1)
-        if self.use_biases:
-            c1 = c1 + hv['postprocess1_bias']
-        t2 = torch.relu(c1)
+        t2 = engine.channel_affine_op(c1, None, hv.get('postprocess1_bias'), relu=True)
         if self.normalize:
             with variable_scope(pscope, absolute=True):
                 t2 = normalize(t2, self.is_training, self.normalize, 'normalize_postprocess2', self.store)
         c2 = cc(t2, hv['postprocess2'], 1)
         if self.use_biases:
-            c2 = c2 + hv['postprocess2_bias']
+            c2 = bias_add(c2, hv['postprocess2_bias'])
         return c2
 
 

@@ -47,6 +47,80 @@ def test_normaliser_variants(gpu, method):
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 5e-5 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize('method,skip', [('bn', False), ('bn', True), ('in', False)])
+def test_normalisers_with_trained_statistics(gpu, method, skip):
+    """SURVEY 8 f-4 with NON-trivial normaliser parameters (gamma / beta / moving statistics as a checkpoint would hold
+    them).  'bn' at inference is folded into the packed weights (modules.WaveNet.folded_variables: every batch norm sits
+    next to a convolution; the one on the residual output scales the identity branch and is carried as a diagonal
+    re-scaling of the stream), so the net stays on the FUSED kernels; 'in' runs the un-fused path on HIP ops only
+    (pwv_instance_norm_f32, pwv_gate_f32, ...).  Both against the fp64 oracle (modules.py:263-284)."""
+    import torch
+    from pwv_amd import engine
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    cfg = small_cfg(normalize_wavenet=method, normalize=method, normalize_cond=method, use_skip_connection=skip)
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=2))
+    mel, z = O.synthetic_inputs(2, 320, cfg)
+    mel_t, z_t = torch.from_numpy(mel).to(gpu), torch.from_numpy(z).to(gpu)
+    model = IAFVocoder(batch_size=2, length=320, store=store)
+    model(None, mel_t, is_training=False, z=z_t)            # creates the normaliser variables (identity-initialised)
+    g = torch.Generator().manual_seed(11)
+    n_norm = 0
+    for name, v in store.vars.items():
+        leaf = name.rsplit('/', 1)[1]
+        if leaf in ('gamma', 'moving_variance'):
+            v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(gpu))
+            n_norm += 1
+        elif leaf in ('beta', 'moving_mean') and ('normalize' in name or 'batch_normalization' in name):
+            v.copy_((torch.randn(v.shape, generator=g) * 0.2).to(gpu))
+    assert n_norm >= 20
+    store.version += 1
+    w = store.numpy()
+    want = O.iaf_vocoder_forward(w, mel, z, cfg)
+    # the oracle really used the randomised parameters (guards against a naming mismatch silently meaning "identity")
+    assert np.abs(want - O.iaf_vocoder_forward(O.init_weights(cfg, seed=2), mel, z, cfg)).max() > 1e-3
+    log = []
+    orig = engine.run_nets
+    engine.run_nets = lambda *a, **k: (log.append(1), orig(*a, **k))[1]
+    try:
+        got = model(None, mel_t, is_training=False, z=z_t)
+        model.verify()
+    finally:
+        engine.run_nets = orig
+    assert (len(log) == cfg.n_iaf) == (method == 'bn')       # 'bn': one fused run_nets per flow; 'in': the un-fused path
+    err = np.abs(got.cpu().numpy() - want).max()
+    assert err <= 5e-5 * max(1.0, np.abs(want).max()), err
+    if method == 'bn':
+        for prec in ('f32',):
+            m32 = IAFVocoder(batch_size=2, length=320, store=store, precision=prec)
+            e32 = np.abs(m32(None, mel_t, is_training=False, z=z_t).cpu().numpy() - want).max()
+            assert e32 <= 5e-5 * max(1.0, np.abs(want).max()), e32
+
+
+def test_instance_norm_op_matches_fp64_and_is_repeatable(gpu):
+    """pwv_instance_norm_f32 alone: moments over time per (utterance, channel), eps 1e-8 (modules.py:274-284), odd sizes,
+    a long time axis (many partial-sum chunks), large mean / small variance (fp64 accumulation), bitwise repeatable."""
+    import torch
+    from pwv_amd import engine
+    rng = np.random.RandomState(0)
+    for n, t, c in ((1, 7, 3), (3, 320, 64), (2, 5000, 80), (1, 300000, 64), (2, 1000, 130)):
+        x = (rng.randn(n, t, c) * rng.uniform(0.01, 3.0, size=(1, 1, c)) + rng.uniform(-50, 50, size=(1, 1, c))).astype(np.float32)
+        gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.randn(c).astype(np.float32)
+        x64 = x.astype(np.float64)
+        mean, var = x64.mean(axis=1, keepdims=True), x64.var(axis=1, keepdims=True)
+        want = gamma * (x64 - mean) / np.sqrt(var + 1e-8) + beta
+        xt = torch.from_numpy(x).to(gpu)
+        y1 = engine.instance_norm_op(xt, torch.from_numpy(gamma).to(gpu), torch.from_numpy(beta).to(gpu))
+        y2 = engine.instance_norm_op(xt, torch.from_numpy(gamma).to(gpu), torch.from_numpy(beta).to(gpu))
+        assert torch.equal(y1, y2)
+        # fp32 input quantisation of a value near 50 limits the result to ~1e-6 * 50 / sigma
+        tol = 2e-5 * max(1.0, np.abs(want).max())
+        assert np.abs(y1.cpu().numpy() - want).max() <= tol, (n, t, c)
+
+
 def test_generate_end_to_end_with_tf_checkpoint(gpu, tmp_path, monkeypatch):
     """generate('bench/c1') restores a TensorFlow-format checkpoint by variable name (EMA shadows win), runs
     the HIP forward and writes wav / npy files; the result equals the oracle run on the EMA weights."""
