@@ -329,6 +329,18 @@ int pwv_add_f32(const float* a, const float* b, float* out, int64_t n, pwv_strea
 int pwv_gate_f32(const float* f, const float* g, float* out, int64_t n, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * wav -> (normalised) dB mel-spectrogram, the conditioning input of generate.py           data_load.py:51-54
+ *   audio.wav2melspec_db (audio.py:341-356): |STFT| (librosa.stft: centred, reflect-padded; `window` is the analysis
+ *   window already zero-padded to n_fft) -> mel_basis [n_mels, 1 + n_fft/2] (librosa.filters.mel, audio.py:241) ->
+ *   amplitude_to_db (10 log10 max(amin^2, .^2), then clipped to top_db below the utterance maximum) -> if `normalise`:
+ *   (clip((db - min_db) / (max_db - min_db), 0, 1) - 0.5) * 2  (audio.py:254-286).
+ *   wav [N, L] -> mel [N, 1 + L/hop, n_mels]; fp64 accumulation inside; n_fft even, <= 2048.
+ * ------------------------------------------------------------------------------------- */
+int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* mel_basis, float* mel, int N, int L, int n_fft,
+                          int hop, int n_mels, float amin, float top_db, float max_db, float min_db, int normalise,
+                          pwv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation, no per-sample condition,
  * PWV_PREC_F16X3) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
  * (modules.py:138-143) without a kernel boundary, a weight-staging phase and a ramp-up / ramp-down per layer.

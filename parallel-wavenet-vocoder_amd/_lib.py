@@ -16,7 +16,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_ROOT = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so')   # PWV_LIB: A/B another build
 CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip',
-                                                    'pwv_stack_persist.hip', 'pwv_norm.hip')]
+                                                    'pwv_stack_persist.hip', 'pwv_norm.hip', 'pwv_audio.hip')]
 
 PWV_MAX_NETS = 2
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
     'pwv_linear_split_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_range_check_f32',
     'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32',
-    'pwv_instance_norm_workspace_bytes', 'pwv_instance_norm_f32', 'pwv_channel_affine_f32', 'pwv_add_f32', 'pwv_gate_f32',
+    'pwv_wav_to_mel_db_f32', 'pwv_instance_norm_workspace_bytes', 'pwv_instance_norm_f32', 'pwv_channel_affine_f32', 'pwv_add_f32', 'pwv_gate_f32',
 )
 
 
@@ -188,6 +188,7 @@ def _declare(lib):
     lib.pwv_pack_head_f32.argtypes = [f32p] * 6 + [c_int, c_int, f32p, c_void_p]
     lib.pwv_wavenet_head_f32.argtypes = [POINTER(HeadArgs), c_void_p]
     lib.pwv_wavenet_stack_f32.argtypes = [POINTER(StackArgs), POINTER(c_void_p)]
+    lib.pwv_wav_to_mel_db_f32.argtypes = [f32p, f32p, f32p, f32p, c_int, c_int, c_int, c_int, c_int] + [ctypes.c_float] * 4 + [c_int, c_void_p]
     lib.pwv_instance_norm_workspace_bytes.restype = c_size_t
     lib.pwv_instance_norm_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.pwv_instance_norm_f32.argtypes = [f32p, f32p, c_int, c_int, c_int, f32p, f32p, ctypes.c_float, c_void_p, c_size_t, c_void_p]

@@ -11,8 +11,11 @@ arithmetic lives in librosa 0.5.1 (requirements.txt; not installable here):
     (clip((db - min_db)/(max_db - min_db), 0, 1) - 0.5) * 2
 
 so the mel has exactly 1 + length/hop frames and values in [-1, 1], which is what the network
-was trained on.  This is CPU-side data preparation, not part of the timed path.  Parity with
-librosa is by construction from its documented algorithms (no librosa here to diff against);
+was trained on.  File reading, trimming and padding are host-side data preparation; the spectrogram itself
+(STFT -> mel -> dB -> normalisation) also exists as a HIP kernel (`wav_to_mel_device`, csrc/pwv_audio.hip) so that
+generate() on wav input keeps the mel on the device; the numpy functions below are its restatement and its test
+reference.  Parity with librosa is by construction from its documented algorithms (no librosa here to diff against; the
+STFT is checked against scipy.signal.stft and the filterbank against hand-derived constants in tests/test_audio_frontend.py);
 resampling uses scipy's polyphase filter where librosa used resampy (only matters when the file's
 rate differs from hp.signal.sr).
 """
@@ -130,6 +133,44 @@ def wav2melspec_db(wav, sr, n_fft, win_length, hop_length, n_mels, max_db=None, 
     if max_db and min_db:
         db = normalize_db(db, max_db, min_db)
     return db.T.astype(np.float32)
+
+
+def analysis_window(n_fft: int, win_length: int) -> np.ndarray:
+    """Periodic hann of win_length, centred in n_fft (what librosa.stft builds from win_length < n_fft)."""
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+    lpad = (n_fft - win_length) // 2
+    return np.pad(win, (lpad, n_fft - win_length - lpad))
+
+
+_device_consts = {}
+
+
+def wav_to_mel_device(wav, normalise: bool = True):
+    """wav [N, L] float32 on the GPU -> normalised dB mel [N, 1 + L/hop, n_mels] on the GPU (pwv_wav_to_mel_db_f32),
+    with the current hparams' signal settings."""
+    import torch
+    from . import _lib, engine
+    s = hp.signal
+    wav = engine._require_cuda_f32(wav, 'wav')
+    if wav.dim() != 2:
+        raise ValueError('wav must be [N, L], got %s' % (tuple(wav.shape),))
+    n, length = wav.shape
+    key = (wav.device, s.sr, s.n_fft, s.win_length, s.n_mels)
+    if key not in _device_consts:
+        _device_consts[key] = (torch.from_numpy(analysis_window(s.n_fft, s.win_length).astype(np.float32)).to(wav.device),
+                               torch.from_numpy(mel_filterbank(s.sr, s.n_fft, s.n_mels).astype(np.float32)).to(wav.device))
+    window, basis = _device_consts[key]
+    mel = torch.empty((n, 1 + length // s.hop_length, s.n_mels), dtype=torch.float32, device=wav.device)
+    _lib.check(_lib.lib().pwv_wav_to_mel_db_f32(wav.data_ptr(), window.data_ptr(), basis.data_ptr(), mel.data_ptr(), n, length, s.n_fft,
+                                                s.hop_length, s.n_mels, 1e-5, 80.0, float(s.max_db), float(s.min_db), int(normalise),
+                                                engine._stream()), 'pwv_wav_to_mel_db_f32')
+    return mel
+
+
+def load_wav_fixed(path: str, length: int) -> np.ndarray:
+    """data_load.py:42-50 at generation time: read, trim, first chunk, zero-pad to exactly `length` samples."""
+    wav = trim_wav(read_wav(path, hp.signal.sr))
+    return fix_length(wav[:length], length).astype(np.float32)
 
 
 def wav_to_normalized_mel(path: str, length: int):

@@ -54,6 +54,15 @@ def _load_mels(data_path, batch_size, length, device):
     split = int(len(files) * hp.train.dataset_ratio)
     files = (files[split:] or files)[:batch_size]
     print('dataset size is {}'.format(len(files)))
+    if all(not f.endswith('.npy') for f in files):
+        # wav input: host reads / trims / pads (data_load.py:42-50), then the spectrogram is computed ON THE DEVICE
+        # (audio_frontend.wav_to_mel_device) -- the mel never visits the host between the front-end and the network
+        from .audio_frontend import load_wav_fixed, wav_to_mel_device
+        wavs = [load_wav_fixed(f, length) for f in files]
+        while len(wavs) < batch_size:
+            wavs.append(wavs[-1])
+        gt = np.stack(wavs)
+        return gt[..., None], wav_to_mel_device(torch.from_numpy(gt).to(device))
     mels, wavs = [], []
     for f in files:
         if f.endswith('.npy'):

@@ -68,3 +68,47 @@ def test_wav_file_to_mel(tmp_path):
     # resampling path: an 8 kHz file comes back at hp.signal.sr
     wavfile.write(path, 8000, (wav[::2] * 32767).astype(np.int16))
     assert abs(len(A.read_wav(path, 16000)) - 2 * sr) <= 2
+
+
+def test_stft_matches_scipy_signal_stft():
+    """The restated librosa.stft (centred, reflect padding, hann(400) zero-padded to 512, hop 80; audio.py:133-134) against
+    scipy.signal.stft configured the same way (boundary='even' is numpy's 'reflect'; scipy divides by the window sum)."""
+    from scipy.signal import stft
+    rng = np.random.RandomState(3)
+    sr, n_fft, win, hop = 16000, 512, 400, 80
+    wav = (0.3 * rng.randn(8000) + 0.2 * np.sin(2 * np.pi * 700 * np.arange(8000) / sr)).astype(np.float32)
+    window = A.analysis_window(n_fft, win)
+    _, _, z = stft(wav.astype(np.float64), fs=sr, window=window, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary='even',
+                   padded=False, return_onesided=True)
+    want = np.abs(z) * window.sum()
+    got = A.stft_mag(wav, n_fft, win, hop)
+    assert got.shape == (257, 101)
+    assert want.shape[1] >= got.shape[1] and np.abs(got - want[:, :got.shape[1]]).max() <= 1e-9 * max(1.0, want.max())
+
+
+def test_slaney_filterbank_against_hand_derived_constants():
+    """tests/golden/slaney_mel_16k_512_80.json holds the 82 band edges and sample filter weights derived with plain Python
+    floats from the Slaney formulas (linear below 1 kHz, log above, unit-area triangles): librosa.filters.mel's documented
+    construction (audio.py:241)."""
+    import json
+    import os
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'slaney_mel_16k_512_80.json')))
+    assert abs(float(A._hz_to_mel(8000.0)) - fix['mel_max']) < 1e-9 and abs(fix['mel_max'] - (15 + 27 * np.log(8) / np.log(6.4))) < 1e-9
+    pts = A._mel_to_hz(np.linspace(0.0, fix['mel_max'], 82))
+    assert np.abs(pts - np.array(fix['mel_points_hz'])).max() < 1e-7
+    fb = A.mel_filterbank(fix['sr'], fix['n_fft'], fix['n_mels'])
+    n = 0
+    for m, pairs in fix['weights'].items():
+        for b, w in pairs:
+            assert abs(fb[int(m), int(b)] - w) < 1e-12
+            n += 1
+    assert n >= 25
+
+
+def test_amplitude_to_db_reference_semantics():
+    """librosa.amplitude_to_db(S) = power_to_db(S**2, amin=amin**2) with top_db relative to the array maximum."""
+    s = np.array([[3.0, 1e-7], [0.02, 0.5]])
+    db = A.amplitude_to_db(s)
+    want = np.array([[20 * np.log10(3.0), 0.0], [20 * np.log10(0.02), 20 * np.log10(0.5)]])
+    want[0, 1] = max(-100.0, want.max() - 80.0)
+    assert np.allclose(db, want, atol=1e-12)

@@ -327,3 +327,29 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
         assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 3 and j['value'] > 0
         assert 'utterance-sharded x2' in j['config']['parallelism'] and 'cpu_baseline' not in j
         assert 'scattered over 2 ranks' in j['sharded_generate'] and j['f32_exact']['value'] > 0
+
+
+def test_device_mel_frontend_matches_numpy_restatement(gpu):
+    """pwv_wav_to_mel_db_f32 (STFT -> Slaney mel -> dB -> [-1, 1]) against the numpy restatement of
+    data_load.py:51-54 / audio.py:102-141,232-243,254-286,341-356 on speech-like and edge-case signals; <= 1e-5."""
+    import torch
+    from pwv_amd import audio_frontend as A
+    from pwv_amd.hparam import hparam as hp
+    hp.set_hparam_yaml('default')
+    s = hp.signal
+    rng = np.random.RandomState(5)
+    L = 16000
+    t = np.arange(L) / s.sr
+    wavs = np.stack([
+        (0.3 * np.sin(2 * np.pi * 220 * t) * np.exp(-3 * t) + 0.05 * rng.randn(L)),         # decaying tone + noise
+        0.8 * rng.randn(L) * (t > 0.3),                                                    # silence then loud noise (top_db clip)
+        np.concatenate([np.zeros(L // 2), 1e-4 * rng.randn(L // 2)]),                       # near the amin floor
+        np.sign(np.sin(2 * np.pi * 50 * t)) * 0.5,                                         # square wave: many harmonics
+    ]).astype(np.float32)
+    want = np.stack([A.wav2melspec_db(w, s.sr, s.n_fft, s.win_length, s.hop_length, s.n_mels, max_db=s.max_db, min_db=s.min_db) for w in wavs])
+    got = A.wav_to_mel_device(torch.from_numpy(wavs).to(gpu)).cpu().numpy()
+    assert got.shape == want.shape == (4, 201, 80)
+    assert np.abs(got - want).max() <= 1e-5
+    raw_want = np.stack([A.wav2melspec_db(w, s.sr, s.n_fft, s.win_length, s.hop_length, s.n_mels) for w in wavs[:1]])
+    raw_got = A.wav_to_mel_device(torch.from_numpy(wavs[:1]).to(gpu), normalise=False).cpu().numpy()
+    assert np.abs(raw_got - raw_want).max() <= 5e-4                                       # dB units, before normalisation
