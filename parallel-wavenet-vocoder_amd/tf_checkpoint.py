@@ -55,7 +55,7 @@ def _put_varint(v: int) -> bytes:
 _CRC_TABLE = None
 
 
-def crc32c(data: bytes) -> int:
+def _crc_table():
     global _CRC_TABLE
     if _CRC_TABLE is None:
         tbl = []
@@ -65,13 +65,67 @@ def crc32c(data: bytes) -> int:
                 c = (c >> 1) ^ 0x82f63b78 if c & 1 else c >> 1
             tbl.append(c)
         _CRC_TABLE = tbl
-    c = 0xffffffff
+    return _CRC_TABLE
+
+
+def _crc_update(c: int, data: bytes) -> int:
+    tbl = _crc_table()
     for b in data:
-        c = _CRC_TABLE[(c ^ b) & 0xff] ^ (c >> 8)
-    return c ^ 0xffffffff
+        c = tbl[(c ^ b) & 0xff] ^ (c >> 8)
+    return c
 
 
-def masked_crc(data: bytes) -> int:
+def _gf2_times(mat, vec: int) -> int:
+    out, i = 0, 0
+    while vec:
+        if vec & 1:
+            out ^= mat[i]
+        vec >>= 1
+        i += 1
+    return out
+
+
+def _zeros_operator(nbytes: int):
+    """The 32x32 GF(2) matrix that advances a raw CRC-32C register over `nbytes` zero bytes (zlib's crc32_combine
+    construction with the Castagnoli polynomial)."""
+    odd = [0x82f63b78] + [1 << i for i in range(31)]            # operator for one zero BIT
+    sq = lambda m: [_gf2_times(m, m[i]) for i in range(32)]
+    op = sq(sq(sq(odd)))                                        # one zero BYTE
+    result = None
+    n = nbytes
+    while n:
+        if n & 1:
+            result = op if result is None else [_gf2_times(op, result[i]) for i in range(32)]
+        n >>= 1
+        if n:
+            op = sq(op)
+    return result if result is not None else [1 << i for i in range(32)]
+
+
+def crc32c(data) -> int:
+    """CRC-32C (Castagnoli) of bytes / a uint8 buffer.  Large buffers are cut into equal chunks whose registers advance in
+    lockstep as numpy vectors (one table lookup per byte POSITION instead of per byte) and are then combined with the
+    zero-advance operator -- pure Python would take ~1 s per MB."""
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1).view(np.uint8)
+    n = buf.size
+    if n < 1 << 14:
+        return _crc_update(0xffffffff, buf.tobytes()) ^ 0xffffffff
+    lanes = int(min(4096, n // 2048))
+    chunk = n // lanes
+    tbl = np.array(_crc_table(), dtype=np.uint32)
+    body = buf[:lanes * chunk].reshape(lanes, chunk)
+    regs = np.zeros(lanes, dtype=np.uint32)
+    regs[0] = 0xffffffff                                        # only the first chunk carries the initial register
+    for i in range(chunk):
+        regs = tbl[(regs ^ body[:, i]) & 0xff] ^ (regs >> 8)
+    op = _zeros_operator(chunk)
+    c = int(regs[0])
+    for k in range(1, lanes):
+        c = _gf2_times(op, c) ^ int(regs[k])                    # crc(A || B) register = advance(reg A, |B|) xor reg0(B)
+    return _crc_update(c, buf[lanes * chunk:].tobytes()) ^ 0xffffffff
+
+
+def masked_crc(data) -> int:
     c = crc32c(data)
     return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff
 
@@ -105,14 +159,37 @@ def _snappy_decompress(src: bytes) -> bytes:
             ln = (tag >> 2) + 1
             off = int.from_bytes(src[pos:pos + 4], 'little')
             pos += 4
+        if off == 0 or off > len(out):
+            raise ValueError('snappy: copy offset out of range')
         for _ in range(ln):
             out.append(out[-off])
-    assert len(out) == n, 'snappy: length mismatch'
+    if len(out) != n:
+        raise ValueError('snappy: length mismatch')
+    return bytes(out)
+
+
+def _snappy_compress_literals(data: bytes) -> bytes:
+    """A valid snappy stream made of literals only (what the writer emits for compress=True; real writers also emit
+    copies -- the decoder's copy paths are exercised by hand-built streams in tests/test_tf_checkpoint.py)."""
+    out = bytearray(_put_varint(len(data)))
+    pos = 0
+    while pos < len(data):
+        ln = min(len(data) - pos, 65536)
+        if ln <= 60:
+            out.append((ln - 1) << 2)
+        else:
+            nb = (max(ln - 1, 1).bit_length() + 7) // 8
+            out.append((59 + nb) << 2)
+            out += (ln - 1).to_bytes(nb, 'little')
+        out += data[pos:pos + ln]
+        pos += ln
     return bytes(out)
 
 
 # ---------------------------------------------------------------------------------- table reader
 def _read_block(f: bytes, offset: int, size: int, verify: bool) -> bytes:
+    if offset < 0 or size < 0 or offset + size + 5 > len(f):
+        raise ValueError('checkpoint index: block [%d, +%d) runs past the end of the file (truncated?)' % (offset, size))
     raw = f[offset:offset + size]
     ctype = f[offset + size]
     if verify:
@@ -176,7 +253,7 @@ def _proto_fields(buf: bytes) -> Iterator[Tuple[int, int, object]]:
 
 
 def _parse_entry(buf: bytes):
-    e = {'dtype': 0, 'shape': [], 'shard_id': 0, 'offset': 0, 'size': 0, 'slices': 0}
+    e = {'dtype': 0, 'shape': [], 'shard_id': 0, 'offset': 0, 'size': 0, 'slices': 0, 'crc': None}
     for field, wt, v in _proto_fields(buf):
         if field == 1:
             e['dtype'] = v
@@ -194,28 +271,38 @@ def _parse_entry(buf: bytes):
             e['offset'] = v
         elif field == 5:
             e['size'] = v
+        elif field == 6:
+            e['crc'] = struct.unpack('<I', v)[0]
         elif field == 7:
             e['slices'] += 1
     return e
 
 
-def list_variables(prefix: str, verify: bool = True) -> Dict[str, Tuple[Tuple[int, ...], int]]:
+def _index_items(prefix: str, verify: bool):
     with open(prefix + '.index', 'rb') as f:
         data = f.read()
+    try:
+        return list(_table_items(data, verify))
+    except (IndexError, struct.error) as e:       # a varint / fixed32 read ran off a truncated or garbled block
+        raise ValueError('corrupt TensorFlow checkpoint index %s.index (%s)' % (prefix, e))
+
+
+def list_variables(prefix: str, verify: bool = True) -> Dict[str, Tuple[Tuple[int, ...], int]]:
     out = {}
-    for key, val in _table_items(data, verify):
+    for key, val in _index_items(prefix, verify):
         if key:
             e = _parse_entry(val)
             out[key.decode()] = (tuple(e['shape']), e['dtype'])
     return out
 
 
-def read_tf_checkpoint(prefix: str, verify: bool = True, name_filter=None) -> Dict[str, np.ndarray]:
-    """All (or the filtered) tensors of checkpoint `<prefix>` as {variable name: ndarray}."""
-    with open(prefix + '.index', 'rb') as f:
-        data = f.read()
+def read_tf_checkpoint(prefix: str, verify: bool = True, name_filter=None, skipped: Optional[list] = None) -> Dict[str, np.ndarray]:
+    """All (or the filtered) tensors of checkpoint `<prefix>` as {variable name: ndarray}.  `verify`: check the block
+    checksums of the index and every tensor's crc32c.  Entries this reader does not materialise (string tensors,
+    partitioned variables) are appended to `skipped` -- callers that need every variable must look at it (generate()
+    checks coverage against the model's variables)."""
     num_shards, entries = 1, {}
-    for key, val in _table_items(data, verify):
+    for key, val in _index_items(prefix, verify):
         if not key:
             for field, _, v in _proto_fields(val):
                 if field == 1:
@@ -223,19 +310,37 @@ def read_tf_checkpoint(prefix: str, verify: bool = True, name_filter=None) -> Di
                 if field == 2 and v != 0:
                     raise ValueError('big-endian checkpoints are not supported')
         else:
-            entries[key.decode()] = _parse_entry(val)
+            try:
+                entries[key.decode()] = _parse_entry(val)
+            except (IndexError, ValueError, struct.error) as e:
+                raise ValueError('corrupt TensorFlow checkpoint index %s.index: entry %r (%s)' % (prefix, key, e))
     shards = {}
     out = {}
     for name, e in entries.items():
         if name_filter is not None and not name_filter(name):
             continue
         if e['dtype'] not in _DTYPES or e['slices']:
+            if skipped is not None:
+                skipped.append(name)
             continue                                          # strings / partitioned variables: not on this path
         sid = e['shard_id']
+        if not 0 <= sid < num_shards:
+            raise ValueError('checkpoint %s: %s lives in shard %d of %d' % (prefix, name, sid, num_shards))
         if sid not in shards:
-            shards[sid] = np.memmap('%s.data-%05d-of-%05d' % (prefix, sid, num_shards), dtype=np.uint8, mode='r')
-        raw = shards[sid][e['offset']:e['offset'] + e['size']]
+            path = '%s.data-%05d-of-%05d' % (prefix, sid, num_shards)
+            if not os.path.exists(path):
+                raise FileNotFoundError('checkpoint %s: data shard %s is missing' % (prefix, os.path.basename(path)))
+            shards[sid] = np.memmap(path, dtype=np.uint8, mode='r') if os.path.getsize(path) else np.zeros(0, np.uint8)
         dt = np.dtype(_DTYPES[e['dtype']])
+        want = int(np.prod(e['shape'], dtype=np.int64)) * dt.itemsize if e['shape'] else dt.itemsize
+        if e['size'] != want:
+            raise ValueError('checkpoint %s: %s has %d bytes for shape %s %s' % (prefix, name, e['size'], e['shape'], dt))
+        if e['offset'] + e['size'] > shards[sid].size:
+            raise ValueError('checkpoint %s: %s [%d, +%d) runs past the end of shard %d (%d bytes): truncated data file'
+                             % (prefix, name, e['offset'], e['size'], sid, shards[sid].size))
+        raw = np.asarray(shards[sid][e['offset']:e['offset'] + e['size']])
+        if verify and e['crc'] is not None and masked_crc(raw) != e['crc']:
+            raise ValueError('checkpoint %s: crc32c mismatch in the bytes of %s (corrupt data shard %d)' % (prefix, name, sid))
         arr = np.frombuffer(raw.tobytes(), dtype=dt.newbyteorder('<'))
         out[name] = arr.reshape(e['shape']).astype(dt)
     return out
@@ -279,32 +384,39 @@ def _build_block(items, restart_interval: int = 16) -> bytes:
     return bytes(out)
 
 
-def write_tf_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], block_entries: int = 64) -> None:
-    """Write {name: array} as a single-shard V2 checkpoint (uncompressed blocks), readable by
-    read_tf_checkpoint and laid out like tensorflow::BundleWriter's output."""
+def write_tf_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], block_entries: int = 64, num_shards: int = 1,
+                        compress: bool = False) -> None:
+    """Write {name: array} as a V2 checkpoint laid out like tensorflow::BundleWriter's output: tensors dealt round-robin
+    over `num_shards` data files, every entry with its masked crc32c, index blocks optionally snappy-framed."""
     def field(n, wt, payload):
         return _put_varint((n << 3) | wt) + payload
 
-    data_path = '%s.data-%05d-of-%05d' % (prefix, 0, 1)
-    items = [(b'', field(1, 0, _put_varint(1)) + field(2, 0, _put_varint(0)) +
+    items = [(b'', field(1, 0, _put_varint(num_shards)) + field(2, 0, _put_varint(0)) +
               field(3, 2, _put_varint(2) + field(1, 0, _put_varint(1))))]
-    offset = 0
-    with open(data_path, 'wb') as df:
-        for name in sorted(tensors):
+    files = [open('%s.data-%05d-of-%05d' % (prefix, k, num_shards), 'wb') for k in range(num_shards)]
+    offsets = [0] * num_shards
+    try:
+        for i, name in enumerate(sorted(tensors)):
             arr = np.asarray(tensors[name], order='C')          # (ascontiguousarray would turn scalars into shape (1,))
             raw = arr.astype(arr.dtype.newbyteorder('<')).tobytes()
+            sid = i % num_shards
             shape = b''.join(field(2, 2, (lambda d: _put_varint(len(d)) + d)(field(1, 0, _put_varint(int(s))))) for s in arr.shape)
             entry = (field(1, 0, _put_varint(_DTYPE_CODES[arr.dtype])) + field(2, 2, _put_varint(len(shape)) + shape) +
-                     field(4, 0, _put_varint(offset)) + field(5, 0, _put_varint(len(raw))) +
-                     field(6, 5, struct.pack('<I', masked_crc(raw) if len(raw) <= (1 << 16) else 0)))
+                     (field(3, 0, _put_varint(sid)) if sid else b'') +
+                     field(4, 0, _put_varint(offsets[sid])) + field(5, 0, _put_varint(len(raw))) +
+                     field(6, 5, struct.pack('<I', masked_crc(raw))))
             items.append((name.encode(), entry))
-            df.write(raw)
-            offset += len(raw)
+            files[sid].write(raw)
+            offsets[sid] += len(raw)
+    finally:
+        for f in files:
+            f.close()
     out = bytearray()
 
     def emit(block: bytes) -> bytes:
-        handle = _put_varint(len(out)) + _put_varint(len(block))
-        out.extend(block + b'\x00' + struct.pack('<I', masked_crc(block + b'\x00')))
+        body, ctype = (_snappy_compress_literals(block), b'\x01') if compress else (block, b'\x00')
+        handle = _put_varint(len(out)) + _put_varint(len(body))
+        out.extend(body + ctype + struct.pack('<I', masked_crc(body + ctype)))
         return handle
 
     index_items = []

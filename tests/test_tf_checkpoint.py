@@ -4,6 +4,8 @@ vector, varints, footer size) and (b) a round trip through an independent writer
 BundleWriter (prefix-compressed keys, restart arrays, multi-block index, EMA names)."""
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -72,3 +74,103 @@ def test_latest_checkpoint_and_store_loading(tmp_path):
     store = VariableStore(device='cpu')
     assert store.load_checkpoint(str(tmp_path / 'model-5'), use_ema=True) == 1
     assert float(store.vars['a/w'][0, 0]) == 7.0                  # EMA shadow preferred (generate.py:59-63)
+
+
+def _tensors(rng):
+    return {'iaf_vocoder/iaf0/scalar/dilated_stack/layer0/filter': rng.randn(2, 64, 64).astype(np.float32),
+            'iaf_vocoder/iaf0/scalar/dilated_stack/layer0/filter/ExponentialMovingAverage': rng.randn(2, 64, 64).astype(np.float32),
+            'iaf_vocoder/cond/dense': rng.randn(1, 80, 80).astype(np.float32),
+            'big/table': rng.randn(1200, 1100).astype(np.float32),          # 5.3 MB: > 4 MB, crosses many crc chunks
+            'global_step': np.array(123456, dtype=np.int64), 'empty': np.zeros((0, 3), np.float32),
+            'beta1_power': np.array(0.9, dtype=np.float32)}
+
+
+@pytest.mark.parametrize('num_shards,compress,block_entries', [(1, False, 64), (3, False, 2), (2, True, 3), (1, True, 1)])
+def test_multi_shard_and_snappy_framed_indexes(tmp_path, num_shards, compress, block_entries):
+    """What a real tensorpack ModelSaver checkpoint can look like (generate.py:55-66 restores it): several
+    .data-0000k-of-0000N shards, snappy-framed index blocks, many small index blocks, a > 4 MB variable, scalars and
+    empty tensors -- every tensor's crc32c is verified on read."""
+    rng = np.random.RandomState(1)
+    t = _tensors(rng)
+    prefix = str(tmp_path / 'model-7')
+    T.write_tf_checkpoint(prefix, t, block_entries=block_entries, num_shards=num_shards, compress=compress)
+    assert sorted(os.path.basename(p) for p in __import__('glob').glob(prefix + '.data-*')) == \
+        ['model-7.data-%05d-of-%05d' % (k, num_shards) for k in range(num_shards)]
+    got = T.read_tf_checkpoint(prefix)
+    assert set(got) == set(t)
+    for k in t:
+        assert got[k].dtype == t[k].dtype and got[k].shape == t[k].shape and np.array_equal(got[k], t[k])
+    assert T.list_variables(prefix)['big/table'][0] == (1200, 1100)
+
+
+def test_snappy_decoder_copy_ops():
+    """The decoder paths real snappy writers use and the literal-only test writer does not: 1-byte-offset copies (incl. an
+    overlapping run), 2-byte-offset copies, long literals; and malformed streams are rejected."""
+    # literal "abcd"; kind-1 copy (1-byte offset) len 4 off 4; kind-1 copy len 9 off 1 (overlapping run of 'd');
+    # kind-2 copy (2-byte offset) len 5 off 8
+    body = bytes([(4 - 1) << 2]) + b'abcd' + bytes([((4 - 4) << 2) | 1, 4]) + bytes([((9 - 4) << 2) | 1, 1]) + \
+        bytes([((5 - 1) << 2) | 2, 8, 0])
+    sofar = b'abcd' + b'abcd' + b'd' * 9
+    want = sofar + sofar[-8:][:5]
+    assert T._snappy_decompress(bytes([len(want)]) + body) == want
+    long_lit = bytes(range(256)) * 3
+    assert T._snappy_decompress(T._snappy_compress_literals(long_lit)) == long_lit
+    with pytest.raises(ValueError):
+        T._snappy_decompress(bytes([8, (4 - 1) << 2]) + b'abcd' + bytes([((4 - 4) << 2) | 1, 9]))      # offset beyond the output
+    with pytest.raises(ValueError):
+        T._snappy_decompress(bytes([9, (4 - 1) << 2]) + b'abcd')                                       # declared length mismatch
+
+
+def test_corruption_and_truncation_fail_cleanly(tmp_path):
+    rng = np.random.RandomState(2)
+    t = _tensors(rng)
+    prefix = str(tmp_path / 'm')
+    T.write_tf_checkpoint(prefix, t, num_shards=2)
+    shard1 = prefix + '.data-00001-of-00002'
+    raw = open(shard1, 'rb').read()
+    # a flipped bit inside a tensor: crc32c mismatch names the variable
+    bad = bytearray(raw)
+    bad[len(bad) // 2] ^= 0x10
+    open(shard1, 'wb').write(bytes(bad))
+    with pytest.raises(ValueError, match='crc32c mismatch'):
+        T.read_tf_checkpoint(prefix)
+    assert 'big/table' in T.read_tf_checkpoint(prefix, verify=False)            # explicit opt-out still reads
+    # a truncated shard
+    open(shard1, 'wb').write(raw[:len(raw) // 3])
+    with pytest.raises(ValueError, match='truncated data file'):
+        T.read_tf_checkpoint(prefix)
+    # a missing shard
+    os.remove(shard1)
+    with pytest.raises(FileNotFoundError, match='data-00001-of-00002'):
+        T.read_tf_checkpoint(prefix)
+    open(shard1, 'wb').write(raw)
+    assert set(T.read_tf_checkpoint(prefix)) == set(t)
+    # a truncated / garbled index: ValueError, never IndexError / struct.error
+    idx = open(prefix + '.index', 'rb').read()
+    for cut in (len(idx) - 1, len(idx) // 2, 60, 10):
+        open(prefix + '.index', 'wb').write(idx[:cut])
+        with pytest.raises(ValueError):
+            T.read_tf_checkpoint(prefix)
+    garbled = bytearray(idx)
+    garbled[5] ^= 0xff
+    open(prefix + '.index', 'wb').write(bytes(garbled))
+    with pytest.raises(ValueError):
+        T.read_tf_checkpoint(prefix)
+
+
+def test_ema_preference_and_skipped_entries(tmp_path):
+    """EMA shadows win when asked for (generate.py:59-63); Adam slots are filtered out by the loader."""
+    from pwv_amd.variables import VariableStore
+    rng = np.random.RandomState(3)
+    t = _tensors(rng)
+    t['iaf_vocoder/cond/dense/Adam'] = np.zeros((1, 80, 80), np.float32)
+    prefix = str(tmp_path / 'ck')
+    T.write_tf_checkpoint(prefix, t, num_shards=2, compress=True)
+    store = VariableStore(device='cpu')
+    n = store.load_checkpoint(prefix, use_ema=True)
+    name = 'iaf_vocoder/iaf0/scalar/dilated_stack/layer0/filter'
+    assert np.array_equal(store.vars[name].numpy(), t[name + '/ExponentialMovingAverage'])
+    assert 'iaf_vocoder/cond/dense/Adam' not in store.vars and n == len(t) - 2
+    store2 = VariableStore(device='cpu')
+    store2.load_checkpoint(prefix, use_ema=False)
+    assert np.array_equal(store2.vars[name].numpy(), t[name])
