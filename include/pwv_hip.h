@@ -192,6 +192,14 @@ int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dens
 /* column order of P: map[col] = channel index into [filter(0..63) ‖ gate(64..127)] */
 int pwv_proj_column_map(int* map128);
 
+/* One layer's 128 columns of the frame-rate projection operands, packed on the device:
+ *   proj_w [C, 128*n_layers] (+ column 128*layer): gc_filter ‖ gc_gate [1,C,64] each, in the P column order, pre-multiplied by
+ *   the exp2 scales of the gate (-2 log2 e for filter columns, -log2 e for gate columns); proj_b [128*n_layers]: the same
+ *   for filter_bias ‖ gate_bias [64] (zeros when NULL).  gc_* may be NULL (no conditioning: only proj_b is written).
+ *   P = frames @ proj_w + proj_b is then one pwv_linear_*_f32 call per net (modules.py:216-228, hoisted to frame rate). */
+int pwv_pack_proj_f32(const float* gc_filter, const float* gc_gate, const float* filter_bias, const float* gate_bias, int C,
+                      int layer, int n_layers, float* proj_w, float* proj_b, pwv_stream_t stream);
+
 typedef struct pwv_layer_args {
     int G;                                 /* nets in this launch (1 or 2) */
     const float* x_in[PWV_MAX_NETS];       /* tile32, N*T rows x 64 */

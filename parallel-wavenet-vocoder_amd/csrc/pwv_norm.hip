@@ -121,6 +121,29 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     }
 }
 
+// One layer's slice of the frame-rate projection weights: column `col` of the kernels' P layout is channel
+// map(col) of [filter (0..63) | gate (64..127)], pre-multiplied by the exp2 scale of its half (pwv_layer_common.h).
+//   proj_w[c, col0 + col] = k(col) * gc_{filter|gate}[c, ch]      (c < C; skipped when gc_filter == NULL)
+//   proj_b[col0 + col]    = k(col) * {filter|gate}_bias[ch]       (0 when the biases are NULL)
+__global__ void pack_proj_kernel(const float* __restrict__ gc_filter, const float* __restrict__ gc_gate,
+                                 const float* __restrict__ filter_bias, const float* __restrict__ gate_bias, int C, int col0, int row_stride,
+                                 float* __restrict__ proj_w, float* __restrict__ proj_b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (c, col), c == C is the bias row
+    if (i >= (C + 1) * 128) return;
+    const int c = i >> 7, col = i & 127;
+    const int h = col >> 6, it = (col >> 4) & 3, r = col & 15;
+    const int ch = chan_of(it, r, h);                          // 0..127 in [filter | gate]
+    const bool is_gate = ch >= 64;
+    const float k = is_gate ? -1.4426950408889634f : -2.8853900817779268f;
+    if (c == C) {
+        const float* b = is_gate ? gate_bias : filter_bias;
+        proj_b[col0 + col] = b ? k * b[ch & 63] : 0.f;
+    } else if (gc_filter) {
+        const float* w = is_gate ? gc_gate : gc_filter;
+        proj_w[(size_t)c * row_stride + col0 + col] = k * w[c * 64 + (ch & 63)];
+    }
+}
+
 static inline unsigned nblocks(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
 
 }  // namespace pwv
@@ -158,6 +181,18 @@ int pwv_gate_f32(const float* f, const float* g, float* out, int64_t n, pwv_stre
     PWV_CHECK_ARG(f && g && out && n >= 0, "pwv_gate_f32: bad arguments");
     if (n == 0) return PWV_OK;
     hipLaunchKernelGGL(gate_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, f, g, out, (long long)n);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_pack_proj_f32(const float* gc_filter, const float* gc_gate, const float* filter_bias, const float* gate_bias, int C, int layer,
+                      int n_layers, float* proj_w, float* proj_b, pwv_stream_t stream) {
+    PWV_CHECK_ARG(proj_b && layer >= 0 && layer < n_layers && C >= 0, "pwv_pack_proj_f32: bad arguments");
+    PWV_CHECK_ARG((gc_filter == nullptr) == (gc_gate == nullptr) && (filter_bias == nullptr) == (gate_bias == nullptr),
+                  "pwv_pack_proj_f32: filter / gate tensors come in pairs");
+    PWV_CHECK_ARG(!gc_filter || (proj_w && C >= 1), "pwv_pack_proj_f32: proj_w / C missing");
+    hipLaunchKernelGGL(pack_proj_kernel, dim3(nblocks((long long)(C + 1) * 128, 256)), dim3(256), 0, (hipStream_t)stream, gc_filter, gc_gate,
+                       filter_bias, gate_bias, gc_filter ? C : 0, layer * 128, n_layers * 128, proj_w, proj_b);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

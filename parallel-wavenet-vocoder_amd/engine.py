@@ -304,16 +304,15 @@ class NetPlan:
         self.layer_floats = lib.pwv_layer_packed_floats(int(use_skip), cond_c)
         self.packed_layers = torch.empty((L, self.layer_floats), dtype=torch.float32, device=dev)
         s = _stream()
-        colmap = torch.tensor(_lib.proj_column_map(), dtype=torch.long, device=dev)
-        # the kernels gate on exp2 arguments: filter columns carry -2*log2(e), gate columns -log2(e)
-        # (csrc/pwv_layer_common.h: kFScale / kGScale; the packed filter/gate weights carry them too)
-        fg_scale = torch.cat([torch.full((64,), -2.8853900817779268), torch.full((64,), -1.4426950408889634)]).to(
-            device=dev, dtype=torch.float32)
+        # the frame-rate projection operands (gc_filter|gc_gate and filter_bias|gate_bias of every layer, in the kernels'
+        # column order, exp2 scales folded in) are packed by one small HIP launch per layer (pwv_pack_proj_f32)
+        cc = net.condition_channels if cond_mode == 'frames' else 0
+        self.proj_b = torch.empty((128 * L,), dtype=torch.float32, device=dev)
+        self.proj_w = torch.empty((cc, 128 * L), dtype=torch.float32, device=dev) if cc else None
         # normalize='bn' (inference): every batch norm of the net is folded into these tensors (WaveNet.folded_variables)
         folded = net.folded_variables(cond_mode != 'none') if net.normalize == 'bn' else None
         self._lv = (lambda j: folded['layers'][j]) if folded else (lambda j: net.layer_variables(j, with_cond=cond_mode != 'none'))
         self._hv = folded['head'] if folded else net.head_variables()
-        proj_w, proj_b = [], []
         for j in range(L):
             v = self._lv(j)
             check(lib.pwv_pack_layer_f32(_ptr(v['filter']), _ptr(v['gate']), _ptr(v['dense']), _ptr(v.get('dense_bias')),
@@ -323,16 +322,9 @@ class NetPlan:
                                          _ptr(v.get('gc_gate')) if cond_c else None,
                                          int(use_skip), cond_c, precision, _ptr(self.packed_layers[j]), s),
                   'pwv_pack_layer_f32')
-            if 'filter_bias' in v:
-                b = torch.cat([v['filter_bias'], v['gate_bias']])
-            else:
-                b = torch.zeros(128, dtype=torch.float32, device=dev)
-            proj_b.append((b * fg_scale)[colmap])
-            if cond_mode == 'frames':
-                wfg = torch.cat([v['gc_filter'][0], v['gc_gate'][0]], dim=1)      # [C, 128]
-                proj_w.append((wfg * fg_scale)[:, colmap])
-        self.proj_b = torch.cat(proj_b).contiguous()                              # [128*L]
-        self.proj_w = torch.cat(proj_w, dim=1).contiguous() if proj_w else None   # [C, 128*L]
+            check(lib.pwv_pack_proj_f32(_ptr(v['gc_filter']) if cc else None, _ptr(v['gc_gate']) if cc else None,
+                                        _ptr(v.get('filter_bias')), _ptr(v.get('gate_bias')), cc, j, L, _ptr(self.proj_w), _ptr(self.proj_b), s),
+                  'pwv_pack_proj_f32')
         hv = self._hv
         last = self._lv(L - 1)
         self.head_floats = lib.pwv_head_packed_floats(net.out_channels)
