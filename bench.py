@@ -454,6 +454,8 @@ def main():
                     # the PMC passes count bytes per launch of one net; a G = 2 launch moves twice that
                     common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
                     common['traffic_source'] = os.path.relpath(tpath, ROOT)
+                    if 'rocprof_kernel_us' in tj:
+                        common['rocprof_kernel_us'] = tj['rocprof_kernel_us']
             if args.precision == 'f32':
                 # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
                 result['roofline'] = dict(kernel='layer_f32_kernel (fused gated-residual layer, %d nets/launch)' % nets_per_launch,

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-2 profile set (run on the GPU box through gpurun from the repo root):
+#   gpurun --timeout 900 -- 'tools/profile_round2.sh r02_e'
+# Raw rocprofv3 output goes to gpurun_out/<tag>_*; `tools/profile_round2_summarize.sh <tag>` (run locally afterwards) turns it
+# into the committed profiles/<tag>_* files.  Counter passes are separate runs with --kernel-trace only.
+set -u
+export TMPDIR=/tmp
+tag=${1:-r02_x}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp
+B="python $R/bench.py --no-cpu-baseline --no-f32-exact"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- $B --steps 10 --warmup 2 \
+    > $R/gpurun_out/${tag}_stats.log 2>&1 < /dev/null
+PWV_PERSIST=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats_persist -- $B --steps 10 --warmup 2 \
+    > $R/gpurun_out/${tag}_stats_persist.log 2>&1 < /dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${tag}_pmc_$c -- $B --steps 3 --warmup 1 --no-graph \
+        > $R/gpurun_out/${tag}_pmc_$c.log 2>&1 < /dev/null
+done
+i=0
+for grp in \
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}_sq_$i -- $B --steps 2 --warmup 1 --no-graph \
+        > $R/gpurun_out/${tag}_sq_$i.log 2>&1 < /dev/null
+    PWV_PERSIST=1 timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}_sqp_$i -- $B --steps 2 --warmup 1 --no-graph \
+        > $R/gpurun_out/${tag}_sqp_$i.log 2>&1 < /dev/null
+done
+cd $R
+python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err < /dev/null
+PWV_PERSIST=1 python bench.py --no-cpu-baseline > gpurun_out/${tag}_bench_persist.json 2> gpurun_out/${tag}_bench_persist.err < /dev/null
+ls gpurun_out | grep ${tag}
