@@ -33,7 +33,10 @@
 namespace pwv {
 
 constexpr int kSlot = kA1Size + kA2Size;   // floats per LDS half: filter|gate (hi+lo) + dense (hi+lo) = 81,920 B
-constexpr int kRing = 3;                   // strip buffers per (net, XCD)
+#ifndef PWV_RING
+#define PWV_RING 2
+#endif
+constexpr int kRing = PWV_RING;            // strip buffers per (net, XCD)
 constexpr int kMaxPLayers = 32;
 constexpr int kSpinLimit = 1 << 17;        // polls before a wave gives up (~0.1-0.3 s)
 constexpr int kCtlWg = 64;                 // ints of control state per workgroup: [p] newest layer resident in LDS half p, [2 + j] done[j]
@@ -64,7 +67,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // -DPWV_PTRACE: every wave accumulates s_memtime cycles per phase: [0] whole loop, [1] TOP wait (vmcnt(0)), [2] RAW spins,
 // [3] WAR spins, [4] leave_layer, [5] weight-ready spins, [6] units, [7] RAW spins taken, [8] first task at, [9] last task done at
 #ifdef PWV_PTRACE
-#define PT_DECL long long pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = 0; (void)pt_t; long long pt_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_p = 0;
+#define PT_DECL long long pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = 0; (void)pt_t; long long pt_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_p = 0; long long pt_top[6] = {0, 0, 0, 0, 0, 0}; long long pt_q = 0;
+#define PT_TOP0() pt_q = __builtin_amdgcn_s_memtime()
+#define PT_TOP(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); pt_top[k] += n_ - pt_q; pt_q = n_; } while (0)
 // phase stamps: pt_ph[k] accumulates the cycles between PT_PHASE(k-1) and PT_PHASE(k) (PT_PHASE0 opens an iteration)
 #define PT_PHASE0() pt_p = __builtin_amdgcn_s_memtime()
 #define PT_PHASE(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); pt_ph[k] += n_ - pt_p; pt_p = n_; } while (0)
@@ -78,6 +83,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PT_ADD(k, v) do {} while (0)
 #define PT_PHASE0() do {} while (0)
 #define PT_PHASE(k) do {} while (0)
+#define PT_TOP0() do {} while (0)
+#define PT_TOP(k) do {} while (0)
 #endif
 
 __device__ __forceinline__ int ld_word(const int* p) {
@@ -219,8 +226,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 for (int e = 0; e < 4; ++e) xb[4 * g + e] = keep ? v[e] : 0.f;
             }
         };
+#ifdef PWV_ABL_NOXB
+#pragma unroll
+        for (int k = 0; k < 32; ++k) xb[k] = xc[k];
+#else
         if (__all(has_prev)) load_b(true);      // wave-uniform fast path: no select behind the loads, they stay in flight
         else load_b(has_prev);
+#endif
     };
 
     // flags a task waits for.  RAW (j >= 1): units u, (32u-d)>>5, (32u+31-d)>>5 have completed layer j-1 (count >= j).
@@ -233,8 +245,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const int ua = (32 * u - d) >> 5, ub = (32 * u + 31 - d) >> 5;
         q.ra = u; q.rb = ua < 0 ? u : ua; q.rc = ub < 0 ? u : ub;
         q.raw_need = j;                                   // j == 0: always satisfied (flags start at 0)
-        q.war_need = (j >= kRing && j < L - 1) ? j - 1 : 0;
-        const int d2 = dil_of(j >= 2 ? j - 2 : 0);
+        // the ring slot it overwrites held layer j - kRing's output, read by layer j - kRing + 1's tasks
+        q.war_need = (j >= kRing && j < L - 1) ? j - kRing + 2 : 0;
+        const int d2 = dil_of(j >= kRing - 1 ? j - kRing + 1 : 0);
         const int wa = u + (d2 >> 5), wb = u + ((d2 + 31) >> 5);
         q.wa = wa > hi - 1 ? u : wa; q.wb = wb > hi - 1 ? u : wb;
         return q;
@@ -305,9 +318,14 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     pt_acc[8] = pt_start;
 #endif
 
+#ifdef PWV_ABL_SHIFT
+#pragma unroll
+    for (int k_ = 0; k_ < PWV_ABL_SHIFT; ++k_) asm volatile("s_nop 0");      // code-placement probe: 4 bytes each
+#endif
     while (u >= 0 && !dead) {
         // ---- TOP: P row, the next task's flags; then everything this wave has in flight has landed ------------------
         PT_PHASE0();
+        PT_TOP0();
         int row, rc, n, t;
         bool valid;
         unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
@@ -320,18 +338,24 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+#ifdef PWV_ABL_NOP
+                    const f32x4 v = {0.f, 0.f, 0.f, 0.f}; (void)pr;
+#else
                     const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
+#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                 }
         }
+        PT_TOP(0);      // unit_rows + P loads issued
         int j2 = j, base2 = base;
         const int i2 = __builtin_amdgcn_readfirstlane(claim_v);      // claimed an iteration ago
         const int u2 = locate(i2, j2, base2);
         Deps nxt{};
         int f_ra = 0, f_rb = 0, f_rc = 0, f_wa = 0, f_wb = 0, f_ld = 0;
+        if (u2 >= 0) nxt = deps_of(j2, u2);
+#ifndef PWV_ABL_NOFLAGS
         if (u2 >= 0) {
-            nxt = deps_of(j2, u2);
             f_ra = __hip_atomic_load(flags + nxt.ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f_rb = __hip_atomic_load(flags + nxt.rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f_rc = __hip_atomic_load(flags + nxt.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -339,9 +363,14 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             f_wb = __hip_atomic_load(flags + nxt.wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f_ld = __hip_atomic_load(&wgctl[j2 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#else
+        f_ra = f_rb = f_rc = f_wa = f_wb = f_ld = 1 << 20;
+#endif
+        PT_TOP(1);      // claim read, locate, deps, flag loads issued
         PT_BEGIN();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PT_END(1);
+        PT_TOP(2);      // the wait
         PT_ADD(6, 1);
         // the previous unit's stores have reached the L2 (and a refill this wave issued has landed): publish
         if (prev_u >= 0) { st_word(flags + prev_u, prev_j + 1, lane); prev_u = -1; }     // (once: a later re-publish would LOWER a count)
@@ -358,11 +387,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             if (dead) break;
             load_x(j, u, rxb, rxc);
         }
+        PT_TOP(3);      // publish, claim, deferred loads
         const bool raw_ok2 = __builtin_amdgcn_readfirstlane(f_ra) >= nxt.raw_need && __builtin_amdgcn_readfirstlane(f_rb) >= nxt.raw_need &&
                              __builtin_amdgcn_readfirstlane(f_rc) >= nxt.raw_need;
         const bool war_ok2 = __builtin_amdgcn_readfirstlane(f_wa) >= nxt.war_need && __builtin_amdgcn_readfirstlane(f_wb) >= nxt.war_need;
         const bool ld_ok2 = j2 < 2 || __builtin_amdgcn_readfirstlane(f_ld) >= j2;
 
+        PT_TOP(4);      // flag evaluation
         PT_PHASE(0);      // TOP: loads issued, waited, published
         const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
         const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
@@ -405,7 +436,11 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
                 if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
                 if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
-                if (s == 5) load_contig<8>(bdp, bdr);      // lands under the last two k-steps (x[t-d]'s operands are dead by now)
+#ifdef PWV_ABL_NOBD
+                if (s == 5) { for (int k = 0; k < 32; ++k) bdr[k] = 0.f; }
+#else
+                if (s == 5) load_contig<8>(bdp, bdr);
+#endif      // lands under the last two k-steps (x[t-d]'s operands are dead by now)
             },
             [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl); });
 
@@ -452,12 +487,20 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             int shift;
             const __amdgpu_buffer_rsrc_t ro = out_rsrc(j, shift);
             const int oo = toff(row, shift);
+#ifdef PWV_ABL_NOSTORE
+            if (valid && acc2[0][0] == 1.2345e-30f) {      // keeps GEMM2 alive, never true
+#else
             if (valid) {
+#endif
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     const int it = g >> 2, q = g & 3;
                     const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                    #ifdef PWV_ABL_NTSTORE
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, 2);
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, 0);
+#endif
                 }
             }
         }
@@ -485,12 +528,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         pt_acc[9] = __builtin_amdgcn_s_memtime();
         pt_acc[0] = pt_acc[9] - pt_start;
         long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 32;
-        for (int k = 0; k < 10; ++k) tr[16 + k] = pt_ph[k];
+        for (int k = 0; k < 8; ++k) tr[16 + k] = pt_ph[k];
+        for (int k = 0; k < 5; ++k) { tr[24 + k] = pt_top[k]; }
         for (int k = 0; k < 10; ++k) tr[k] = pt_acc[k];
         tr[10] = net; tr[11] = xcc; tr[12] = w;
         tr[13] = pt_entry_rt; tr[14] = pt_start_rt; tr[15] = __builtin_amdgcn_s_memrealtime();
         tr[30] = dead ? 1 : 0; tr[31] = ((long long)j << 32) | (unsigned)u;
-        tr[24] = (long long)flags; tr[25] = (long long)wgctl;
+
     }
 #endif
     if (prev_u >= 0 && !dead) st_word(flags + prev_u, prev_j + 1, lane);

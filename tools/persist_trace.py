@@ -66,6 +66,8 @@ def main():
           'GEMM2 (24 MFMA) + gate', 'WAR check + stores', 'leave_layer / bookkeeping']
     for k, name in enumerate(ph):
         print('  phase %-38s %6.0f cycles per unit (%4.1f %%)' % (name, (t[:, 16 + k] / t[:, 6]).mean(), 100 * t[:, 16 + k].sum() / tot.sum()))
+    for k, name in enumerate(['unit_rows + P loads issued', 'claim read, locate, deps, flag loads issued', 'wait vmcnt(0)', 'publish, claim, deferred loads', 'flag evaluation']):
+        print('    TOP part %-46s %6.0f cycles per unit' % (name, (t[:, 24 + k] / t[:, 6]).mean()))
     print('  units that had to spin on RAW: %.2f %%' % (100 * t[:, 7].sum() / t[:, 6].sum()))
     # chip-wide 100 MHz clock: absolute picture in microseconds from the first wave's entry
     t0 = t[:, 13].min()

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-2 profile set (run on the GPU box through gpurun from the repo root):
 #   gpurun --timeout 900 -- 'tools/profile_round2.sh r02_e'
-# Raw rocprofv3 output goes to gpurun_out/<tag>_*; `tools/profile_round2_summarize.sh <tag>` (run locally afterwards) turns it
-# into the committed profiles/<tag>_* files.  Counter passes are separate runs with --kernel-trace only.
+# Raw rocprofv3 output goes to gpurun_out/<tag>_* on the box and is summarised there into gpurun_out/<tag>_profiles/ (the
+# only part that travels back); copy those files into profiles/.  Counter passes are separate runs with --kernel-trace only.
 set -u
 export TMPDIR=/tmp
 tag=${1:-r02_x}
@@ -30,4 +30,7 @@ done
 cd $R
 python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err < /dev/null
 PWV_PERSIST=1 python bench.py --no-cpu-baseline > gpurun_out/${tag}_bench_persist.json 2> gpurun_out/${tag}_bench_persist.err < /dev/null
-ls gpurun_out | grep ${tag}
+# summarise here (the raw kernel traces are too big to travel back), keep only the summaries
+tools/profile_round2_summarize.sh ${tag} gpurun_out/${tag}_profiles
+rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_stats_persist gpurun_out/${tag}_pmc_* gpurun_out/${tag}_sq_* gpurun_out/${tag}_sqp_*
+ls gpurun_out/${tag}_profiles
