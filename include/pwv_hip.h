@@ -350,7 +350,7 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
 
 /* ---------------------------------------------------------------------------------------
  * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation, no per-sample condition,
- * PWV_PREC_F16X3) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
+ * PWV_PREC_F16X3 or PWV_PREC_F32) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
  * (modules.py:138-143) without a kernel boundary, a weight-staging phase and a ramp-up / ramp-down per layer.
  *   x_in[g]  input of the run's first layer, x_out[g] output of its last layer (both full-size tile32 buffers,
  *   N*T rows x 64); layer j of the run reads packed_layers[g] + j*packed_layer_stride and the P columns
@@ -378,6 +378,7 @@ typedef struct pwv_persist_args {
     int cond_hop, cond_offset, cond_frames;
     void* workspace;
     size_t workspace_bytes;
+    int precision;                                /* PWV_PREC_F16X3 or PWV_PREC_F32 (packed_layers packed accordingly) */
 } pwv_persist_args;
 
 size_t pwv_persist_workspace_bytes(int G, int N, int T, int n_layers, const int* dilations);

@@ -131,6 +131,7 @@ class PersistArgs(Structure):
         ('cond_hop', c_int), ('cond_offset', c_int), ('cond_frames', c_int),
         ('workspace', c_void_p),
         ('workspace_bytes', c_size_t),
+        ('precision', c_int),
     ]
 
 

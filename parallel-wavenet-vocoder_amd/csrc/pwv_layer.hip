@@ -74,43 +74,6 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
     }
 }
 
-// lds fragment: 4 consecutive k-steps of row tile `it` for this lane (one ds_read_b128)
-__device__ __forceinline__ f32x4 frag(const float* lds, int base, int it, int ngroups, int g, int lane) {
-    return *reinterpret_cast<const f32x4*>(&lds[base + ((it * ngroups + g) * 64 + lane) * 4]);
-}
-
-// One GEMM as NG groups of (NIT row tiles x 4 k-steps) MFMAs.  The A fragments of group g+1
-// are read while group g's MFMAs issue; sched_barrier(0) pins that order so the scheduler
-// cannot hoist all ds_reads (which spills).  `a` enters holding group 0's fragments and leaves
-// holding whatever `tail(a)` loaded during the last group (the next GEMM's group 0).
-//   bval(ks): B register of k-step ks;  extra(g): VALU work to overlap with group g's MFMAs.
-template <int NG, int NIT, int IT0, int ITSTEP, int NACC, typename BF, typename EF, typename TF>
-__device__ __forceinline__ void gemm_groups(const float* lds, int base, int lane, f32x16 (&acc)[NACC], f32x4 (&a)[4],
-                                            BF&& bval, EF&& extra, TF&& tail) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        f32x4 n[4] = {a[0], a[1], a[2], a[3]};
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) n[i] = frag(lds, base, IT0 + i * ITSTEP, NG, g + 1, lane);
-        } else {
-            tail(n);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // reads first: a whole group of MFMAs covers their latency
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float b = bval(g * 4 + e);
-#pragma unroll
-            for (int i = 0; i < NIT; ++i)
-                acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b, acc[IT0 + i * ITSTEP], 0, 0, 0);
-        }
-        extra(g);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = n[i];
-    }
-}
-
 // Work is handed out in 32-row units (one MFMA column tile = one wave's worth of samples).
 // WAVES = 4: one wave per SIMD with up to 512 registers; units are strided statically and the next
 //            unit's operands are prefetched into registers under the current unit's GEMM2.

@@ -217,6 +217,45 @@ __device__ __forceinline__ void load_contig(const float* __restrict__ p, float (
 }
 
 
+// ---- exact-fp32 MFMA building blocks (pwv_layer.hip, pwv_stack_persist.hip) ------------------------------------------
+// lds fragment: 4 consecutive k-steps of row tile `it` for this lane (one ds_read_b128)
+__device__ __forceinline__ f32x4 frag(const float* lds, int base, int it, int ngroups, int g, int lane) {
+    return *reinterpret_cast<const f32x4*>(&lds[base + ((it * ngroups + g) * 64 + lane) * 4]);
+}
+
+// One GEMM as NG groups of (NIT row tiles x 4 k-steps) MFMAs.  The A fragments of group g+1
+// are read while group g's MFMAs issue; sched_barrier(0) pins that order so the scheduler
+// cannot hoist all ds_reads (which spills).  `a` enters holding group 0's fragments and leaves
+// holding whatever `tail(a)` loaded during the last group (the next GEMM's group 0).
+//   bval(ks): B register of k-step ks;  extra(g): VALU work to overlap with group g's MFMAs.
+template <int NG, int NIT, int IT0, int ITSTEP, int NACC, typename BF, typename EF, typename TF>
+__device__ __forceinline__ void gemm_groups(const float* lds, int base, int lane, f32x16 (&acc)[NACC], f32x4 (&a)[4],
+                                            BF&& bval, EF&& extra, TF&& tail) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        f32x4 n[4] = {a[0], a[1], a[2], a[3]};
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) n[i] = frag(lds, base, IT0 + i * ITSTEP, NG, g + 1, lane);
+        } else {
+            tail(n);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // reads first: a whole group of MFMAs covers their latency
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float b = bval(g * 4 + e);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b, acc[IT0 + i * ITSTEP], 0, 0, 0);
+        }
+        extra(g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = n[i];
+    }
+}
+
+
 // launchers of the split-fp16 variants (pwv_layer_f16.hip)
 int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, int per_net, hipStream_t s);
 int launch_head_f16x3(const HeadParams& hp, bool from_gated, int grid, hipStream_t s);

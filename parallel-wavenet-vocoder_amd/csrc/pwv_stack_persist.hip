@@ -109,6 +109,7 @@ __device__ __forceinline__ bool spin_ge(const int* p, int need, int* status, int
     return false;
 }
 
+template <bool F32>
 __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * kSlot];
 #ifdef PWV_PTRACE
@@ -395,88 +396,137 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
 
         PT_TOP(4);      // flag evaluation
         PT_PHASE(0);      // TOP: loads issued, waited, published
-        const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
-        const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
         const float* bdp = packed_n + (size_t)j * p.packed_stride + kBD + h * 32;
-
-        f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
-        float xc[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) xc[k] = rxc[k];
-        split8<0>(rxb, bh[0], bl[0]);
-        split8<8>(rxb, bh[1], bl[1]);
-        split8<16>(rxb, bh[2], bl[2]);
-        split8<24>(rxb, bh[3], bl[3]);
-        auto bxh = [&](int s) -> f16x8 { return bh[s]; };
-        auto bxl = [&](int s) -> f16x8 { return bl[s]; };
-        float o[32];
         float bdr[32];           // dense bias of this lane's 32 output channels (global memory: the LDS is full of weights)
-        f16x8 oh[4], ol[4];
-        f16x8 ah[4], al[4];
-
-        PT_PHASE(1);      // x[t-d] split
-        // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]); x[t] is split under its first four MFMA groups ------------
-        first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
-        gemm16<8, 2, 0, 2, 4>(
-            A1, lane, acc, ah, al, bxh, bxl,
-            [&](int s) {
-                if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
-                if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
-                if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
-                if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
-            },
-            [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
-        PT_PHASE(2);      // GEMM1 pair 0
-        // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -----------------------------------
-        gemm16<8, 2, 1, 2, 4>(
-            A1, lane, acc, ah, al, bxh, bxl,
-            [&](int s) {
-                o[2 * s] = gate_act(acc[0][2 * s], acc[2][2 * s]);
-                o[2 * s + 1] = gate_act(acc[0][2 * s + 1], acc[2][2 * s + 1]);
-                asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
-                if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
-                if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
-#ifdef PWV_ABL_NOBD
-                if (s == 5) { for (int k = 0; k < 32; ++k) bdr[k] = 0.f; }
-#else
-                if (s == 5) load_contig<8>(bdp, bdr);
-#endif      // lands under the last two k-steps (x[t-d]'s operands are dead by now)
-            },
-            [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl); });
-
-        PT_PHASE(3);      // GEMM1 pair 1
-        // ---- GEMM2: dense 64 -> 64, accumulator starts at x[t] + dense_bias ---------------------------------------------
+        float o[32];
         f32x16 acc2[2];
+        // the next task's rows: requested between GEMM1 and GEMM2, in flight under GEMM2 + gating + stores
+        auto prefetch_next = [&]() {
+            if (u2 >= 0 && raw_ok2) {
+                load_x(j2, u2, rxb, rxc);
+            } else {      // nothing prefetched: last task of this wave, or the next task's producers are still at work
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bdr[it * 16 + q * 4 + e];
+                for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
             }
-        asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
-        // the next task's rows: in flight under GEMM2 + gating + stores (xc is dead from here on)
-        if (u2 >= 0 && raw_ok2) {
-            load_x(j2, u2, rxb, rxc);
-        } else {      // nothing prefetched: last task of this wave, or the next task's producers are still at work
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (F32) {
+            // ---- exact-fp32 arithmetic: v_mfma_f32_32x32x2_f32, the operands are the rows as loaded (pwv_layer.hip) ----
+            const float* Af = lds + (j & 1) * kSlot;                 // [kA1 | kA2] of this layer's packed block
+            f32x4 a[4];
+            auto bx = [&](int ks) -> float { return ks < 32 ? rxb[ks] : rxc[ks - 32]; };
+            PT_PHASE(1);
+            a[0] = frag(Af, 0, 0, 16, 0, lane);
+            a[1] = frag(Af, 0, 2, 16, 0, lane);
+            gemm_groups<16, 2, 0, 2>(Af, 0, lane, acc, a, bx, [](int) {}, [&](f32x4(&n)[4]) {
+                n[0] = frag(Af, 0, 1, 16, 0, lane);
+                n[1] = frag(Af, 0, 3, 16, 0, lane);
+            });
+            PT_PHASE(2);
+            gemm_groups<16, 2, 1, 2>(
+                Af, 0, lane, acc, a, bx,
+                [&](int g) {
+                    o[g] = gate_act(acc[0][g], acc[2][g]);
+                    asm volatile("" : "+v"(o[g]));   // keep the gating inside this MFMA group (no sinking)
+                    if (g == 10) load_contig<8>(bdp, bdr);
+                },
+                [&](f32x4(&n)[4]) {
+                    n[0] = frag(Af, kA1Size, 0, 8, 0, lane);
+                    n[1] = frag(Af, kA1Size, 1, 8, 0, lane);
+                });
+            PT_PHASE(3);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        PT_PHASE(4);      // acc2 init + prefetch issue
-        gemm16<4, 2, 0, 1, 2>(
-            A2, lane, acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
-            [&](int s) {
-                if (s < 2) {   // k-steps 0,1 use o tile 0; gate + split tile 1 under them
+            for (int it = 0; it < 2; ++it)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[16 + 8 * s + e] = gate_act(acc[1][8 * s + e], acc[3][8 * s + e]);
-                    if (s == 0) split8<16>(o, oh[2], ol[2]);
-                    else split8<24>(o, oh[3], ol[3]);
-                    asm volatile("" : "+v"(oh[2 + (s & 1)]), "+v"(ol[2 + (s & 1)]));
-                }
-            },
-            [](f16x8(&)[4], f16x8(&)[4]) {});
+                for (int r = 0; r < 16; ++r) acc2[it][r] = rxc[it * 16 + r] + bdr[it * 16 + r];
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
+            prefetch_next();
+            PT_PHASE(4);
+            gemm_groups<8, 2, 0, 1>(
+                Af, kA1Size, lane, acc2, a, [&](int ks) -> float { return o[ks]; },
+                [&](int g) {
+                    if (g < 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[16 + 4 * g + e] = gate_act(acc[1][4 * g + e], acc[3][4 * g + e]);
+                            asm volatile("" : "+v"(o[16 + 4 * g + e]));
+                        }
+                    }
+                },
+                [](f32x4(&)[4]) {});
+        } else {
+            const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
+            const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
 
+            f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
+            float xc[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) xc[k] = rxc[k];
+            split8<0>(rxb, bh[0], bl[0]);
+            split8<8>(rxb, bh[1], bl[1]);
+            split8<16>(rxb, bh[2], bl[2]);
+            split8<24>(rxb, bh[3], bl[3]);
+            auto bxh = [&](int s) -> f16x8 { return bh[s]; };
+            auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+            f16x8 oh[4], ol[4];
+            f16x8 ah[4], al[4];
+
+            PT_PHASE(1);      // x[t-d] split
+            // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]); x[t] is split under its first four MFMA groups ------------
+            first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
+            gemm16<8, 2, 0, 2, 4>(
+                A1, lane, acc, ah, al, bxh, bxl,
+                [&](int s) {
+                    if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
+                    if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
+                    if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
+                    if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+                },
+                [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
+            PT_PHASE(2);      // GEMM1 pair 0
+            // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -----------------------------------
+            gemm16<8, 2, 1, 2, 4>(
+                A1, lane, acc, ah, al, bxh, bxl,
+                [&](int s) {
+                    o[2 * s] = gate_act(acc[0][2 * s], acc[2][2 * s]);
+                    o[2 * s + 1] = gate_act(acc[0][2 * s + 1], acc[2][2 * s + 1]);
+                    asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
+                    if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
+                    if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
+#ifdef PWV_ABL_NOBD
+                    if (s == 5) { for (int k = 0; k < 32; ++k) bdr[k] = 0.f; }
+#else
+                    if (s == 5) load_contig<8>(bdp, bdr);
+#endif      // lands under the last two k-steps (x[t-d]'s operands are dead by now)
+                },
+                [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl); });
+
+            PT_PHASE(3);      // GEMM1 pair 1
+            // ---- GEMM2: dense 64 -> 64, accumulator starts at x[t] + dense_bias ---------------------------------------------
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bdr[it * 16 + q * 4 + e];
+                }
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
+            prefetch_next();      // (xc is dead from here on)
+            PT_PHASE(4);      // acc2 init + prefetch issue
+            gemm16<4, 2, 0, 1, 2>(
+                A2, lane, acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
+                [&](int s) {
+                    if (s < 2) {   // k-steps 0,1 use o tile 0; gate + split tile 1 under them
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[16 + 8 * s + e] = gate_act(acc[1][8 * s + e], acc[3][8 * s + e]);
+                        if (s == 0) split8<16>(o, oh[2], ol[2]);
+                        else split8<24>(o, oh[3], ol[3]);
+                        asm volatile("" : "+v"(oh[2 + (s & 1)]), "+v"(ol[2 + (s & 1)]));
+                    }
+                },
+                [](f16x8(&)[4], f16x8(&)[4]) {});
+
+        }
         PT_PHASE(5);      // GEMM2
         // ---- stores (after the readers of the ring slot they overwrite are known to be done) -------------------------------
         PT_BEGIN();
@@ -606,6 +656,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, p.units, p.upx, p.strip_units, p.wpx, p.hu);
     if (rc != PWV_OK) return rc;
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_stack_persist_f32: bad N/T");
+    PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32, "pwv_wavenet_stack_persist_f32: precision must be PWV_PREC_F16X3 or PWV_PREC_F32");
     PWV_CHECK_ARG(a->proj_row_stride % 4 == 0 && a->cond_hop >= 0, "pwv_wavenet_stack_persist_f32: bad projection arguments");
     PWV_CHECK_ARG(a->workspace_bytes >= pwv_persist_workspace_bytes(a->G, a->N, a->T, a->n_layers, a->dilations),
                   "pwv_wavenet_stack_persist_f32: workspace too small");
@@ -644,7 +695,10 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     hipStream_t s = (hipStream_t)stream;
     const size_t n16 = ctl_bytes / 16;
     hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)ws, n16);
-    hipLaunchKernelGGL(stack_persist_kernel, dim3(cus), dim3(512), 0, s, p);
+    if (a->precision == PWV_PREC_F32)
+        hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(cus), dim3(512), 0, s, p);
+    else
+        hipLaunchKernelGGL(stack_persist_kernel<false>, dim3(cus), dim3(512), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "persistent stack kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;

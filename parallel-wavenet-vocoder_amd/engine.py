@@ -398,7 +398,7 @@ def _same_structure(a, b) -> bool:
             and a.condition_channels == b.condition_channels and a.filter_width == b.filter_width)
 
 
-def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s):
+def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec):
     """Layer 0 (one launch), layers 1 .. L-2 (ONE persistent launch), layer L-1 with the head behind it (one launch); all
     nets of the flow in every launch, all on the current stream."""
     G, L = len(nets), plans[0].n_layers
@@ -417,7 +417,7 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         la.skip_init = 1
         la.N, la.T, la.dilation = n, t, int(net0.dilations[j])
         la.cond_hop, la.cond_offset, la.cond_frames = hop, offset, frames
-        la.precision = _lib.PREC_F16X3
+        la.precision = prec
         return la
 
     la = layer_args(0, 0, 1)
@@ -439,6 +439,7 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
     pa.packed_layer_stride = stride
     pa.proj_row_stride = row_stride
     pa.N, pa.T = n, t
+    pa.precision = prec
     pa.cond_hop, pa.cond_offset, pa.cond_frames = hop, offset, frames
     nbytes = lib.pwv_persist_workspace_bytes(G, n, t, L - 2, dil)
     if nbytes == 0:
@@ -456,11 +457,20 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
 
     la = layer_args(L - 1, 0, 1)
     la.out_mode = _lib.OUT_GATED
-    for g in range(G):
-        la.head_packed[g] = plans[g].packed_head.data_ptr()
-        la.head_out[g] = outs[g].data_ptr()
-    la.head_q = net0.out_channels
+    if prec == _lib.PREC_F16X3:          # the head runs inside the last layer's launch
+        for g in range(G):
+            la.head_packed[g] = plans[g].packed_head.data_ptr()
+            la.head_out[g] = outs[g].data_ptr()
+        la.head_q = net0.out_channels
     check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
+    if prec != _lib.PREC_F16X3:
+        ha = _lib.HeadArgs()
+        ha.G = G
+        for g in range(G):
+            ha.in_[g], ha.packed[g], ha.out[g] = bufs[g][1].data_ptr(), plans[g].packed_head.data_ptr(), outs[g].data_ptr()
+        ha.N, ha.T, ha.Q = n, t, net0.out_channels
+        ha.in_mode, ha.precision = _lib.HEAD_IN_GATED, prec
+        check(lib.pwv_wavenet_head_f32(ctypes.byref(ha), s), 'pwv_wavenet_head_f32')
 
 
 def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,
@@ -551,8 +561,8 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
     main = torch.cuda.current_stream()
     use_skip = bool(net0.use_skip_connection)
-    persist = (PERSIST and prec == _lib.PREC_F16X3 and mode != 'samples' and not use_skip and max_workgroups == 0 and FUSE_HEAD
-               and _persist_fits(G, rows, L))
+    persist = (PERSIST and (prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
+               and max_workgroups == 0 and _persist_fits(G, rows, L))
     two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
     if mode == 'frames':
@@ -607,7 +617,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
 
     if persist:
         _run_stack_persist(lib, nets, plans, projs, bufs, outs, x if first_fused else None, x_limit, row_stride,
-                           (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s)
+                           (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec)
         return outs
     if two:
         for g in range(2):

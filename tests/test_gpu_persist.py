@@ -37,9 +37,10 @@ def persist_knobs():
     engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE = saved
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('n,t,L,G', [(1, 160000, 10, 2), (1, 16000, 10, 2), (1, 8000, 30, 2), (1, 64000, 30, 1), (1, 2400, 6, 2),
                                      (3, 8000, 10, 2), (5, 1040, 7, 1), (1, 65536, 4, 2)])
-def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G):
+def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G, precision):
     import torch
     engine = persist_knobs
     store, nets = _nets(gpu, L, G)
@@ -47,18 +48,18 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
     x = torch.randn((n, t, 1), generator=g).to(gpu)
     frames = torch.rand((n, t // 80 + 1, 80), generator=g).to(gpu)
     cond = engine.RepeatedCondition(frames, 80, 40, t)
-    engine.run_nets(nets, x, cond)                       # creates the variables
+    engine.run_nets(nets, x, cond, precision=precision)  # creates the variables
     for name in list(store.vars):
         if store.vars[name].dim() == 1:
             store.vars[name].normal_(0, 0.1)
     store.version += 1
     engine.PERSIST = False
-    ref = [o.clone() for o in engine.run_nets(nets, x, cond)]
+    ref = [o.clone() for o in engine.run_nets(nets, x, cond, precision=precision)]
     engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE = True, 0.0      # force the persistent path whatever the size
     log = engine.EVENT_LOG = []
     try:
         for _ in range(3):
-            got = engine.run_nets(nets, x, cond)
+            got = engine.run_nets(nets, x, cond, precision=precision)
             torch.cuda.synchronize()
             assert engine.persist_status() == 0
             for a, b in zip(ref, got):

@@ -18,6 +18,7 @@ def main():
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     G = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+    prec = sys.argv[5] if len(sys.argv) > 5 else None
     dev = torch.device('cuda', 0)
     d10 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
     dil = (d10 * 3)[:L]
@@ -32,7 +33,7 @@ def main():
     frames = torch.rand((1, rows // hop + 1, 80), generator=g).to(dev)
     cond = engine.RepeatedCondition(frames, hop, hop // 2, rows)
     engine.PERSIST_UNITS_PER_WAVE = float(os.environ.get("UPW", "2"))
-    engine.run_nets(nets, x, cond)          # creates variables
+    engine.run_nets(nets, x, cond, precision=prec)          # creates variables
     for name in list(store.vars):
         if store.vars[name].dim() == 1:
             store.vars[name].normal_(0, 0.1)
@@ -41,7 +42,7 @@ def main():
 
     def run(persist):
         engine.PERSIST = persist
-        outs = engine.run_nets(nets, x, cond)
+        outs = engine.run_nets(nets, x, cond, precision=prec)
         torch.cuda.synchronize()
         return [o.clone() for o in outs]
 
@@ -68,12 +69,12 @@ def main():
     for persist in (False, True):
         engine.PERSIST = persist
         for _ in range(2):
-            engine.run_nets(nets, x, cond)
+            engine.run_nets(nets, x, cond, precision=prec)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            engine.run_nets(nets, x, cond)
+            engine.run_nets(nets, x, cond, precision=prec)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
