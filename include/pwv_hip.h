@@ -112,6 +112,11 @@ int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, 
  * ------------------------------------------------------------------------------------- */
 int pwv_range_flag(int** flag);
 int pwv_range_check_f32(const float* x, int64_t n, float limit, int* flag, pwv_stream_t stream);
+/* pack-time statistics of one layer (R = D = 64, S = 128; TF layouts) for the host's bound on the residual stream:
+ * out8 = max|filter|, max|gate|, max|dense|, max|skip|, max|gc_filter|, max|gc_gate| (0 when NULL),
+ *        max_out sum_in |dense| + max|dense_bias|, max_out sum_in |skip| + max|skip_bias|;  C = rows of gc_* */
+int pwv_range_stats_f32(const float* filter, const float* gate, const float* dense, const float* dense_bias, const float* skip,
+                        const float* skip_bias, const float* gc_filter, const float* gc_gate, int C, float* out8, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * "tile32": the layout of every [rows = N*T, C] ACTIVATION buffer the fused kernels below read or
