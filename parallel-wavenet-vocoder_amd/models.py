@@ -141,11 +141,15 @@ class IAFVocoder(object):
             cond = melspec.reshape(n * t_mel, n_mels)
             length = t_mel
             input_channels = n_mels
-            wmats = []
-            for i, stride in enumerate(strides):
-                w = get_variable('transposed_conv_{}_weights'.format(i), (1, stride, C, input_channels if i == 0 else C), store=store)
-                # kernel width == stride: out[t*s + j, co] = sum_ci in[t, ci] * w[0, j, co, ci]  (a GEMM)
-                wmats.append(w[0].permute(2, 0, 1).reshape(w.shape[3], stride * C).contiguous())
+            ws = [get_variable('transposed_conv_{}_weights'.format(i), (1, stride, C, input_channels if i == 0 else C), store=store)
+                  for i, stride in enumerate(strides)]
+            # kernel width == stride: out[t*s + j, co] = sum_ci in[t, ci] * w[0, j, co, ci]  (a GEMM); the [Cin, s*C] operand
+            # is re-laid-out once per weight version, not per forward
+            key = (store.uid, store.version, tuple(strides))
+            if getattr(self, '_tconv_key', None) != key:
+                self._tconv_key = key
+                self._tconv_mats = [w[0].permute(2, 0, 1).reshape(w.shape[3], stride * C).contiguous() for w, stride in zip(ws, strides)]
+            wmats = self._tconv_mats
             if (self.precision or engine.DEFAULT_PRECISION) == 'f16x3':
                 engine.range_check_op(melspec, self._mel_limit(wmats, store))
             for i, stride in enumerate(strides):
