@@ -221,14 +221,14 @@ typedef struct pwv_layer_args {
     int out_mode;                          /* PWV_OUT_RESIDUAL / PWV_OUT_GATED */
     int precision;                         /* PWV_PREC_* */
     int max_workgroups;                    /* 0 = one per CU */
-    /* Layer 0 of a scalar-input net without a materialised causal layer (PWV_PREC_F16X3, no skip accumulation,
+    /* Layer 0 of a scalar-input net without a materialised causal layer (PWV_PREC_F16X3 / PWV_PREC_F32, no skip accumulation,
      * filter width 2): when x_first != NULL, x_in is ignored and the kernel evaluates
      *     h[t] = x_first[t-1] * causal_filter[0,0,:] + x_first[t] * causal_filter[1,0,:]      modules.py:179-180
      * for rows t and t-d itself, with the operations (and bits) of pwv_iaf_front_f32: 4 B instead of 768 B of
      * traffic per sample for this layer and no front launch.  x_first is [N*T] float32 (the flow's input). */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];   /* [2,1,64] each */
-    /* The LAST layer with the post-processing head fused behind it (PWV_PREC_F16X3, out_mode PWV_OUT_GATED, no skip
+    /* The LAST layer with the post-processing head fused behind it (PWV_PREC_F16X3 / PWV_PREC_F32, out_mode PWV_OUT_GATED, no skip
      * accumulation, no per-sample condition): when head_packed[g] != NULL the gated output stays in registers and
      * feeds pwv_wavenet_head_f32's arithmetic directly; head_out[g] receives [N,T,head_q]; x_out is not written. */
     const float* head_packed[PWV_MAX_NETS];     /* pwv_pack_head_f32 output */
@@ -277,7 +277,7 @@ int pwv_wavenet_head_f32(const pwv_head_args* args, pwv_stream_t stream);
  * WaveNet.__call__ (modules.py:138-165) without a host round trip per layer.
  *   buf0[g] holds the causal layer's output on entry; buf0/buf1 ping-pong through the layers;
  *   out[g] receives the net output [N,T,Q].
- * With PWV_PREC_F16X3, no skip accumulation and no per-sample condition the head runs inside the last layer's
+ * With PWV_PREC_F16X3 or PWV_PREC_F32, no skip accumulation and no per-sample condition the head runs inside the last layer's
  * launch (pwv_layer_args.head_packed) unless `separate_head` is set.
  * streams[0] only (streams[1] == NULL): every layer is one launch covering all G nets.
  * Two streams and G == 2: net g's chain runs on streams[g] with `max_workgroups` workgroups per

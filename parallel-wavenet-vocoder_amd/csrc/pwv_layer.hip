@@ -33,10 +33,11 @@ struct TileRegs {
     float cd[COND ? 40 : 4];      // cond[t], this lane's 40 channels
     float sk[SKIP ? 64 : 4];      // running skip sum (D layout)
     int row;                      // flattened row n*T + t of this lane
+    int t;                        // position inside the utterance
     bool valid;
 };
 
-template <bool SKIP, bool COND>
+template <bool SKIP, bool COND, bool FIRST = false>
 __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int unit, int lane,
                                           TileRegs<SKIP, COND>& r, bool skip_load) {
     const int h = lane >> 5;
@@ -49,8 +50,20 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
     const int n = rc / p.T;
     const int t = rc - n * p.T;
     const bool has_prev = t >= p.dilation;            // x[t-d] = 0 left of the utterance start
-    load_tiled<8, 64>(p.x_in[net], rc, h, true, r.xc);
-    load_tiled<8, 64>(p.x_in[net], has_prev ? rc - p.dilation : rc, h, has_prev, r.xb);
+    r.t = t;
+    if constexpr (FIRST) {
+        // the four scalars the two rows are functions of: x[t], x[t-1], x[t-d], x[t-d-1] (zero left of the start);
+        // rebuild_first() turns them into the rows
+        const float* x1 = p.x_first;
+        const int d = p.dilation;
+        r.xc[0] = x1[rc];
+        r.xc[1] = t >= 1 ? x1[rc - (t >= 1 ? 1 : 0)] : 0.f;
+        r.xb[0] = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f;
+        r.xb[1] = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
+    } else {
+        load_tiled<8, 64>(p.x_in[net], rc, h, true, r.xc);
+        load_tiled<8, 64>(p.x_in[net], has_prev ? rc - p.dilation : rc, h, has_prev, r.xb);
+    }
     int prow = 0;
     if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
     load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.pj);
@@ -82,11 +95,22 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
 //            the two waves of a SIMD drift out of phase: one wave's MFMAs cover the other's loads,
 //            gating, address arithmetic and stores (identical streams at equal priority stay in
 //            lockstep and hit their VALU sections together, leaving the matrix pipe idle).
-template <int WAVES, bool SKIP, bool COND, bool GATED>
+// FIRST (layer 0 of a scalar-input net, 8 waves): the causal layer's output is not read but rebuilt from the flow input
+//   with the front kernel's own two fp32 operations per channel (bit-identical to pwv_iaf_front_f32 + this kernel).
+// HEAD  (plain gated last layer, 8 waves): head_f32_kernel<true>'s arithmetic runs behind the gate on the registers the
+//   gated output was accumulated in; LDS holds exactly filter|gate + skip + postprocess1 = 160 KB, so the small vectors
+//   come from global memory and units are handed out statically (no room for the counter).
+template <int WAVES, bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
 __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams p) {
+    static_assert(!(FIRST || HEAD) || WAVES == 8, "FIRST / HEAD: 8-wave kernels only");
+    static_assert(!HEAD || (GATED && !SKIP && !COND && !FIRST), "HEAD: plain last layer only");
+    static_assert(!FIRST || !SKIP, "FIRST: no skip accumulation");
     constexpr bool PREFETCH = WAVES == 4;
-    constexpr int kLds = layer_floats(SKIP, COND);
-    __shared__ __attribute__((aligned(16))) float lds[kLds + 4];   // +4: the unit counter
+    constexpr int kLds = HEAD ? kA1Size + kASSize + kHA1Size : layer_floats(SKIP, COND);
+    constexpr int kCF = kLds + 4;           // FIRST: the causal filter [2][64] behind the unit counter
+    constexpr int kHS = kA1Size;            // HEAD: skip weights, then postprocess1
+    constexpr int kH1 = kA1Size + kASSize;
+    __shared__ __attribute__((aligned(16))) float lds[kLds + (HEAD ? 0 : 4) + (FIRST ? 128 : 0)];   // +4: the unit counter
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,10 +119,19 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
     const int net = blockIdx.x % p.G;
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
-    int* unit_counter = reinterpret_cast<int*>(&lds[kLds]);
+    int* unit_counter = reinterpret_cast<int*>(&lds[HEAD ? 0 : kLds]);      // unused with HEAD
 
-    fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
-    if (tid == 0) *unit_counter = 0;
+    if constexpr (HEAD) {
+        fill_lds<kA1Size / 4, 64 * WAVES>(lds, p.packed[net] + kA1, tid);
+        fill_lds<kASSize / 4, 64 * WAVES>(lds + kHS, p.packed_head[net] + kHAS, tid);
+        fill_lds<kHA1Size / 4, 64 * WAVES>(lds + kH1, p.packed_head[net] + kHA1, tid);
+    } else {
+        fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
+        if (tid == 0) *unit_counter = 0;
+        if constexpr (FIRST) {
+            if (tid < 128) lds[kCF + tid] = p.cfilt[net][tid];
+        }
+    }
     __syncthreads();
 
     constexpr int kAS = kLayerBase;
@@ -128,14 +161,37 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
         load_tile<SKIP, COND>(p, net, unit, lane, cur, skip_load);
     } else {
         if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
-        unit = grab();
+        unit = HEAD ? u_begin + wave : grab();
     }
 
     auto no_extra = [](int) {};
 
     while (unit < u_end) {
         const int next = PREFETCH ? unit + WAVES : 0;
-        if constexpr (!PREFETCH) load_tile<SKIP, COND>(p, net, unit, lane, cur, skip_load);
+        if constexpr (!PREFETCH) load_tile<SKIP, COND, FIRST>(p, net, unit, lane, cur, skip_load);
+        float first_x0 = 0.f, first_x1 = 0.f;      // FIRST: x[t], x[t-1]
+        (void)first_x0;
+        (void)first_x1;
+        if constexpr (FIRST) {
+            // this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; same operation order as
+            // iaf_front_kernel: round(x[t-1] w0), then fma(x[t], w1, .)
+            const float x0 = cur.xc[0], x1v = cur.xc[1], xd0 = cur.xb[0], xd1 = cur.xb[1];
+            first_x0 = x0;
+            first_x1 = x1v;
+            const bool has_prev = cur.t >= p.dilation;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCF + 8 * g + 4 * h]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&lds[kCF + 64 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cur.xc[4 * g + e] = fmaf(x0, w1[e], x1v * w0[e]);
+                    const float vb = fmaf(xd0, w1[e], xd1 * w0[e]);
+                    cur.xb[4 * g + e] = has_prev ? vb : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one filter quad at a time: the scheduler otherwise front-loads all 16 reads
+            }
+        }
         // ---- GEMM1: [F;G][128 x 32t] = W1^T[128 x K] * [x[t-d]; x[t]; (cond[t])] -------------
         // accumulators start at P[frame(t)] (conditioning projection + filter/gate bias)
         f32x16 acc[4];
@@ -188,6 +244,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
                 } else if constexpr (SKIP) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) n[i] = frag(lds, kAS, i, 8, 0, lane);
+                } else if constexpr (HEAD) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) n[i] = frag(lds, kHS, i, 8, 0, lane);
                 }
             });
 
@@ -199,7 +258,56 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
         }
 
         float* orow = p.x_out[net] + tile_off(cur.row, h, 64);
-        if constexpr (GATED) {
+        if constexpr (GATED && HEAD) {
+            // ---- fused head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2, the operations
+            //      (and bits) of head_f32_kernel<true> ------------------------------------------------------------
+            const float* hb = p.packed_head[net];
+            f32x16 accs[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHBS + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+            gemm_groups<8, 4, 0, 1>(lds, kHS, lane, accs, a, [&](int ks) -> float { return o[ks]; }, no_extra,
+                                    [&](f32x4(&n)[4]) {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) n[i] = frag(lds, kH1, i, 16, 0, lane);
+                                    });
+            f32x16 acc1[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHB1 + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = v[e];
+                }
+            gemm_groups<16, 4, 0, 1>(
+                lds, kH1, lane, acc1, a, [&](int ks) -> float { return fmaxf(accs[ks >> 4][ks & 15], 0.f); }, no_extra,
+                [](f32x4(&)[4]) {});
+            const int Q = p.head_q;
+            for (int q = 0; q < Q; ++q) {
+                float part = 0.f;
+                const float* w2 = hb + kHW2 + (h * Q + q) * 64;
+#pragma unroll
+                for (int i4 = 0; i4 < 16; ++i4) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + 4 * i4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * i4 + e;
+                        part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[e], part);
+                    }
+                }
+                part += __shfl_xor(part, 32);
+                part += hb[kHW2 + 2 * Q * 64 + q];
+                if (cur.valid && h == 0) p.head_out[net][(size_t)cur.row * Q + q] = part;
+            }
+        } else if constexpr (GATED) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
             if (cur.valid) {
@@ -217,8 +325,17 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bd = *reinterpret_cast<const f32x4*>(&lds[kBD + h * 32 + it * 16 + q * 4]);
+                    if constexpr (FIRST) {
+                        // x[t] row evaluated again from the two scalars (same operations, same bits) rather than kept live
+                        const int g = it * 4 + q;
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCF + 8 * g + 4 * h]);
+                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(&lds[kCF + 64 + 8 * g + 4 * h]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = cur.xc[it * 16 + q * 4 + e] + bd[e];
+                        for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = fmaf(first_x0, w1[e], first_x1 * w0[e]) + bd[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = cur.xc[it * 16 + q * 4 + e] + bd[e];
+                    }
                 }
             }
             // k-steps 0..15 use o tile 0 (ready); pair 1 is gated under those MFMAs
@@ -278,7 +395,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
             cur = nx;
             unit = next;
         } else {
-            unit = grab();
+            unit = HEAD ? unit + WAVES : grab();
         }
     }
 }
@@ -484,6 +601,15 @@ static int launch_layer(const LayerParams& lp, int per_net4, int per_net8, hipSt
     return PWV_OK;
 }
 
+// the two buffer-removing variants (always 8 waves)
+template <bool COND, bool GATED, bool FIRST, bool HEAD>
+static int launch_layer_fused(const LayerParams& lp, int per_net8, hipStream_t s) {
+    hipLaunchKernelGGL((layer_f32_kernel<8, false, COND, GATED, FIRST, HEAD>), dim3(per_net8 * lp.G), dim3(512), 0, s, lp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "layer kernel launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
 }  // namespace pwv
 
 using namespace pwv;
@@ -574,9 +700,11 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     }
     for (int g = 0; g < a->G; ++g)
         PWV_CHECK_ARG(!any_skip || a->skip[g], "pwv_wavenet_layer_f32: skip must be set for all nets or none");
-    PWV_CHECK_ARG(!a->x_first || a->precision == PWV_PREC_F16X3, "pwv_wavenet_layer_f32: x_first is implemented for PWV_PREC_F16X3 only");
-    PWV_CHECK_ARG(!a->head_packed[0] || (a->precision == PWV_PREC_F16X3 && a->out_mode == PWV_OUT_GATED && a->head_q >= 1 && a->head_q <= kMaxQ),
-                  "pwv_wavenet_layer_f32: a fused head needs PWV_PREC_F16X3, out_mode PWV_OUT_GATED and head_q in [1,%d]", kMaxQ);
+    const bool fusable = a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32;
+    PWV_CHECK_ARG(!a->x_first || (fusable && !any_skip), "pwv_wavenet_layer_f32: x_first needs PWV_PREC_F16X3 or PWV_PREC_F32 and no skip accumulation");
+    PWV_CHECK_ARG(!a->head_packed[0] || (fusable && a->out_mode == PWV_OUT_GATED && !any_skip && !a->cond && !a->x_first && a->head_q >= 1 && a->head_q <= kMaxQ),
+                  "pwv_wavenet_layer_f32: a fused head needs PWV_PREC_F16X3 or PWV_PREC_F32, out_mode PWV_OUT_GATED, no skip accumulation, no per-sample "
+                  "condition and head_q in [1,%d]", kMaxQ);
     lp.head_q = a->head_q;
     lp.x_first = a->x_first;
     lp.x_limit = a->x_limit;
@@ -614,6 +742,11 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
         // 4-wave workgroups with 40 KB (60 KB with cond) of LDS: several per CU
         const int want = per_net * (cond ? 2 : 3);
         return launch_layer_h16(lp, cond, gated, want < nt4 ? want : nt4, s);
+    }
+    if (lp.packed_head[0]) return launch_layer_fused<false, true, false, true>(lp, g8, s);
+    if (lp.x_first) {
+        if (cond) return gated ? launch_layer_fused<true, true, true, false>(lp, g8, s) : launch_layer_fused<true, false, true, false>(lp, g8, s);
+        return gated ? launch_layer_fused<false, true, true, false>(lp, g8, s) : launch_layer_fused<false, false, true, false>(lp, g8, s);
     }
     if (any_skip) {
         if (cond) return gated ? launch_layer<true, true, true>(lp, g4, g8, s) : launch_layer<true, true, false>(lp, g4, g8, s);
@@ -681,8 +814,9 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
         wgs = cus / 2 > 0 ? cus / 2 : 1;
     }
     const bool use_skip = a->skip[0] != nullptr;
-    // split-fp16 path, plain last layer: the head runs inside the last layer's launch (pwv_layer_args.head_packed)
-    const bool fuse_head = !a->separate_head && a->precision == PWV_PREC_F16X3 && !use_skip && !a->cond && a->n_layers >= 2;
+    // split-fp16 and fp32 paths, plain last layer: the head runs inside the last layer's launch (pwv_layer_args.head_packed)
+    const bool fuse_head = !a->separate_head && (a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32) && !use_skip && !a->cond &&
+                           a->n_layers >= 2;
     int cur = 0;
     for (int j = 0; j < a->n_layers; ++j) {
         const bool last = j == a->n_layers - 1;

@@ -455,13 +455,14 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
 
     la = layer_args(L - 1, 0, 1)
     la.out_mode = _lib.OUT_GATED
-    if prec == _lib.PREC_F16X3:          # the head runs inside the last layer's launch
+    fuse_head = prec == _lib.PREC_F16X3 or (prec == _lib.PREC_F32 and FUSE_HEAD)
+    if fuse_head:                        # the head runs inside the last layer's launch
         for g in range(G):
             la.head_packed[g] = plans[g].packed_head.data_ptr()
             la.head_out[g] = outs[g].data_ptr()
         la.head_q = net0.out_channels
     check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
-    if prec != _lib.PREC_F16X3:
+    if not fuse_head:
         ha = _lib.HeadArgs()
         ha.G = G
         for g in range(G):
@@ -583,9 +584,9 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # ---- causal layer (modules.py:174-183) ----------------------------------------------------
     R = net0.residual_channels
     bufs = [[tile_buf(R, torch.float16 if half else torch.float32) for _ in range(2)] for _ in nets]
-    # split-fp16 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself (pwv_layer_args.x_first),
-    # so the [rows, 64] front buffer is neither written nor read
-    first_fused = (FUSE_FIRST and prec == _lib.PREC_F16X3 and qin == 1 and net0.filter_width == 2 and R == 64
+    # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
+    # (pwv_layer_args.x_first), so the [rows, 64] front buffer is neither written nor read
+    first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32) and qin == 1 and net0.filter_width == 2 and R == 64
                    and not net0.use_skip_connection and plans[0].causal_bias is None)
     if prec == _lib.PREC_F16X3 and not first_fused:
         range_check_op(x, x_limit)          # (layer 0 checks its scalar input itself when it rebuilds the causal layer)

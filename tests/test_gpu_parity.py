@@ -369,9 +369,10 @@ def test_vocoder_random_configurations(gpu, seed):
     assert got.shape == want.shape and err <= TOL_F32 * scale, (err, scale, dil, method, shared, precision)
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
-def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, monkeypatch):
-    """Split-fp16 path: layer 0 rebuilds h[t] = x[t-1] w0 + x[t] w1 from the scalar input (pwv_layer_args.x_first)
+def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, precision, monkeypatch):
+    """Both arithmetics: layer 0 rebuilds h[t] = x[t-1] w0 + x[t] w1 from the scalar input (pwv_layer_args.x_first)
     with the front kernel's own two fp32 operations per channel -- switching the front kernel back on must not change
     a single bit (ragged length, several utterances, dilation of layer 0 > 1 in the second flow, a one-layer net)."""
     from pwv_amd import engine
@@ -379,13 +380,13 @@ def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, monkeyp
     weights = O.init_weights(cfg, seed=21)
     mel, z = O.synthetic_inputs(3, 80 * 7, cfg)
     monkeypatch.setattr(engine, 'FUSE_FIRST', True)
-    a = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+    a = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     monkeypatch.setattr(engine, 'FUSE_FIRST', False)
-    b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+    b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     assert np.array_equal(a, b)
     # ... and the same for the head fused behind the last layer (the gated output stays in registers)
     monkeypatch.setattr(engine, 'FUSE_HEAD', False)
-    c = run_vocoder_hip(cfg, weights, mel, z, gpu, precision='f16x3')
+    c = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     assert np.array_equal(a, c)
     assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
 
