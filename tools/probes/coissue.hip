@@ -39,12 +39,12 @@ __global__ __launch_bounds__(512) void k(float* out, int reps, long long* cyc) {
 }
 
 template <int V, bool TRANS, bool AG>
-void run(int threads, float* out, long long* cyc) {
+void run(int threads, float* out, long long* cyc, int grid = 256) {
     int reps = 20000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<V, TRANS, AG>), dim3(256), dim3(threads), 0, 0, out, 200, cyc);
+    hipLaunchKernelGGL((k<V, TRANS, AG>), dim3(grid), dim3(threads), 0, 0, out, 200, cyc);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<V, TRANS, AG>), dim3(256), dim3(threads), 0, 0, out, reps, cyc);
+    hipLaunchKernelGGL((k<V, TRANS, AG>), dim3(grid), dim3(threads), 0, 0, out, reps, cyc);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -52,8 +52,8 @@ void run(int threads, float* out, long long* cyc) {
     hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     double per_group = (double)c / (reps * 8.0);   // cycles per (2 MFMA + 2V VALU) per wave
     double ns_group = ms * 1e6 / (reps * 8.0);
-    double tf = 2.0 * 32 * 32 * 16 * 2 * (reps * 8.0) * (threads / 64) * 256 / (ms * 1e-3) / 1e12;
-    printf("%s waves/SIMD %d  V=%2d %s: %6.1f s_memtime ticks, %6.1f ns per [2 MFMA + %2d VALU] per wave -> tick rate %.2f GHz, %.0f TFLOP/s\n", AG ? "AGPR" : "VGPR", threads / 256, V,
+    double tf = 2.0 * 32 * 32 * 16 * 2 * (reps * 8.0) * (threads / 64) * grid / (ms * 1e-3) / 1e12;
+    printf("grid %3d %s waves/SIMD %d  V=%2d %s: %6.1f s_memtime ticks, %6.1f ns per [2 MFMA + %2d VALU] per wave -> tick rate %.2f GHz, %.0f TFLOP/s\n", grid, AG ? "AGPR" : "VGPR", threads / 256, V,
            TRANS ? "exp" : "fma", per_group, ns_group, 2 * V, per_group / ns_group, tf);
 }
 
@@ -64,6 +64,11 @@ int main() {
         run<0, false, false>(threads, out, cyc); run<4, false, false>(threads, out, cyc); run<8, false, false>(threads, out, cyc); run<16, false, false>(threads, out, cyc);
         run<0, false, true>(threads, out, cyc); run<4, false, true>(threads, out, cyc); run<8, false, true>(threads, out, cyc); run<16, false, true>(threads, out, cyc);
         run<8, true, false>(threads, out, cyc); run<8, true, true>(threads, out, cyc);
+    }
+    // the same on 8 workgroups only: far below the package power cap, so what is left is the issue behaviour alone
+    for (int threads : {256, 512}) {
+        run<0, false, false>(threads, out, cyc, 8); run<4, false, false>(threads, out, cyc, 8); run<8, false, false>(threads, out, cyc, 8);
+        run<16, false, false>(threads, out, cyc, 8); run<8, true, false>(threads, out, cyc, 8);
     }
     return 0;
 }
