@@ -13,6 +13,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
     > $R/gpurun_out/${tag}_stats.log 2>&1 < /dev/null
 PWV_PERSIST=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats_persist -- $B --steps 10 --warmup 2 \
     > $R/gpurun_out/${tag}_stats_persist.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats_f32 -- $B --precision f32 --steps 5 --warmup 2 \
+    > $R/gpurun_out/${tag}_stats_f32.log 2>&1 < /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${tag}_pmc_$c -- $B --steps 3 --warmup 1 --no-graph \
         > $R/gpurun_out/${tag}_pmc_$c.log 2>&1 < /dev/null
@@ -32,5 +34,5 @@ python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_benc
 PWV_PERSIST=1 python bench.py --no-cpu-baseline > gpurun_out/${tag}_bench_persist.json 2> gpurun_out/${tag}_bench_persist.err < /dev/null
 # summarise here (the raw kernel traces are too big to travel back), keep only the summaries
 tools/profile_round2_summarize.sh ${tag} gpurun_out/${tag}_profiles
-rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_stats_persist gpurun_out/${tag}_pmc_* gpurun_out/${tag}_sq_* gpurun_out/${tag}_sqp_*
+rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_stats_persist gpurun_out/${tag}_stats_f32 gpurun_out/${tag}_pmc_* gpurun_out/${tag}_sq_* gpurun_out/${tag}_sqp_*
 ls gpurun_out/${tag}_profiles

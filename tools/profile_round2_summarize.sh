@@ -10,6 +10,8 @@ python tools/summarize_rocprof.py "$(f ${tag}_stats kernel_stats.csv)" $out/${ta
     "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-exact (default: per-layer launches, two streams, HIP-graph replay)"
 python tools/summarize_rocprof.py "$(f ${tag}_stats_persist kernel_stats.csv)" $out/${tag}_kernel_stats_persist.md \
     "the same command with PWV_PERSIST=1 (persistent dataflow launch for the residual layers 1..L-2 of every stack)"
+python tools/summarize_rocprof.py "$(f ${tag}_stats_f32 kernel_stats.csv)" $out/${tag}_kernel_stats_f32.md \
+    "rocprofv3 --kernel-trace --stats -- python bench.py --precision f32 --steps 5 --warmup 2 --no-cpu-baseline --no-f32-exact (exact-fp32 MFMA kernels, FIRST / HEAD fused)"
 python tools/hbm_traffic.py "$(f ${tag}_pmc_FETCH_SIZE counter_collection.csv)" "$(f ${tag}_pmc_WRITE_SIZE counter_collection.csv)" \
     "layer_f16x3_kernel<false, false, false, false, false>" 81920000 $out/${tag}_hbm_traffic.json \
     "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-exact --no-graph" \
