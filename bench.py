@@ -475,10 +475,12 @@ def main():
                 result['roofline'] = dict(kernel='layer_f16x3_kernel<0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
                                           bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
                                           frac=ach_gbs / PEAK_HBM_GBS, **common)
-                result['roofline']['limiter'] = ('package power: rocm-smi reads 1399-1402 W of the 1400 W cap with sclk held at ~1.82 GHz during this '
-                                                 'bench (profiles/r02_power_clock.md); matrix pipe busy 44-46 %, MFMA and VALU issue serial per SIMD '
-                                                 '(profiles/r02_e_sq_counters.md, tools/probes/coissue.hip).  By arithmetic intensity (240 fp16-FLOP/B < 312) '
-                                                 'the HBM roof is the nominal one -- DESIGN.md section 4, K1p')
+                result['roofline']['limiter'] = ('two stacked limits, neither of them HBM: (1) issue -- every VALU instruction takes 2-2.7 cycles of matrix-pipe '
+                                                 'time on a SIMD (tools/probes/coissue.hip, same cycle counts on 8 workgroups at 2.4 GHz), so 120 MFMA + ~700 VALU '
+                                                 'per 32-row unit give 44-46 % matrix-pipe busy (profiles/r02_g_sq_counters.md); (2) clock -- rocm-smi reads '
+                                                 '1399-1402 W of the 1400 W package cap with sclk held at ~1.82 of 2.4 GHz during this bench '
+                                                 '(profiles/r02_power_clock.md).  By arithmetic intensity (240 fp16-FLOP/B < 312) the HBM roof is the nominal one '
+                                                 '-- DESIGN.md section 4, K1 item 6 and K1p')
                 result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
                                            'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
         per_gpu = value / n_gpus
