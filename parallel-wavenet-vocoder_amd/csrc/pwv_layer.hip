@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
     }
 
     auto no_extra = [](int) {};
+    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(p.x_out[net], u_begin, u_end, 64);      // unused with HEAD
 
     while (unit < u_end) {
         const int next = PREFETCH ? unit + WAVES : 0;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        float* orow = p.x_out[net] + tile_off(cur.row, h, 64);
+        const int ooff = units_off(cur.row, h, 64, u_begin);      // (rows past the end are never stored: `valid`)
         if constexpr (GATED && HEAD) {
             // ---- fused head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2, the operations
             //      (and bits) of head_f32_kernel<true> ------------------------------------------------------------
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
+                    store_wt(out_rs, ooff + g * 1024, v);
                 }
             }
         } else {
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
                 for (int g = 0; g < 8; ++g) {
                     const int it = g >> 2, q = g & 3;
                     f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
+                    store_wt(out_rs, ooff + g * 1024, v);
                 }
             }
         }

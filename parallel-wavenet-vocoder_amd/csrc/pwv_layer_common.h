@@ -163,6 +163,29 @@ __host__ __device__ inline size_t tile32_floats(long long rows, int C) { return 
 __device__ __forceinline__ size_t tile_off(int row, int quad, int C) {
     return (size_t)(row >> 5) * (32 * C) + quad * 128 + (row & 31) * 4;
 }
+// Residual-stream stores are WRITE-THROUGH (`sc1`): the line stays valid in the XCD's L2 for the next layer's reads, but
+// it is no longer dirty, so the end-of-kernel release has nothing left to write back -- the ~40 MB a launch stores drain
+// while it computes instead of between it and the dependent launch (measured: -2.6 % per step).  The cache
+// policy bits of a store are only reachable through the buffer intrinsics; the descriptor covers exactly the workgroup's
+// own units [u_begin, u_end), so out-of-range offsets are dropped by the hardware.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxWriteThrough = 16;      // sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t units_rsrc(const float* base, int u_begin, int u_end, int C) {
+    const unsigned long long a = (unsigned long long)(base + (size_t)u_begin * (32 * C));
+    const unsigned long long span = (unsigned long long)(u_end > u_begin ? u_end - u_begin : 0) * (32ull * C * 4);
+    // plain selects + readfirstlane: the descriptor must be provably wave-uniform or every access becomes a waterfall loop
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)(span > 0xffffffffull ? 0xffffffffull : span));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+// byte offset of (row, quad) relative to the first unit of the descriptor
+__device__ __forceinline__ int units_off(int row, int quad, int C, int u_begin) {
+    return (((row >> 5) - u_begin) * (32 * C) + quad * 128 + (row & 31) * 4) * 4;
+}
+__device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, kAuxWriteThrough);
+}
+
 // The same copy by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write pass): wave w moves the 1 KB chunks
 // w, w + WAVES, ...; chunk c lands at lds + 256 c floats + 16 bytes x lane (the destination of an LDS-DMA is
 // wave-uniform base + lane x size, so packed order == LDS order is exactly what it needs).  The transfers count on

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     };
     if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
     auto no_extra = [](int) {};
+    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(p.x_out[net], u_begin, u_end, 64);      // unused with HEAD
 
     // x[t-d] / x[t] rows of one unit -> registers (clamped addresses, zeros left of the utterance start)
     auto load_x = [&](int unit, float (&xb)[32], float (&xc)[32]) {
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             });
 
         PWV_STAMP(5);
-        float* orow = p.x_out[net] + tile_off(row, h, 64);
+        const int ooff = units_off(row, h, 64, u_begin);      // (rows past the end are never stored: `valid`)
         if constexpr (GATED && HEAD) {
             // ---- fused head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2 -------------------
             const float* hb = p.packed_head[net];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
+                    store_wt(out_rs, ooff + g * 1024, v);
                 }
             }
         } else {
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 for (int g = 0; g < 8; ++g) {
                     const int it = g >> 2, q = g & 3;
                     f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(orow + g * 256) = v;
+                    store_wt(out_rs, ooff + g * 1024, v);
                 }
             }
             PWV_STAMP(7);

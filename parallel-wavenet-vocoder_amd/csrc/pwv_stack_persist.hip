@@ -62,7 +62,6 @@ struct PersistParams {
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // -DPWV_PTRACE: every wave accumulates s_memtime cycles per phase: [0] whole loop, [1] TOP wait (vmcnt(0)), [2] RAW spins,
 // [3] WAR spins, [4] leave_layer, [5] weight-ready spins, [6] units, [7] RAW spins taken, [8] first task at, [9] last task done at
