@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
     }
 
     auto no_extra = [](int) {};
-    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(p.x_out[net], u_begin, u_end, 64);      // unused with HEAD
+    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(p.x_out[net], u_begin, u_end, 32 * 64 * 4);      // unused with HEAD
 
     while (unit < u_end) {
         const int next = PREFETCH ? unit + WAVES : 0;
@@ -381,13 +381,14 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
             gemm_groups<8, 4, 0, 1>(lds, kAS, lane, accs, a, [&](int ks) -> float { return o[ks]; }, no_extra,
                                     [](f32x4(&)[4]) {});
             if (cur.valid) {
-                float* srow = p.skip[net] + tile_off(cur.row, h, 128);
+                const __amdgpu_buffer_rsrc_t skip_rs = units_rsrc(p.skip[net], u_begin, u_end, 32 * 128 * 4);
+                const int soff = units_off(cur.row, h, 128, u_begin);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(srow + (8 * it + 2 * q) * 128) = v;
+                        store_wt(skip_rs, soff + (8 * it + 2 * q) * 512, v);
                     }
             }
         }

@@ -170,19 +170,22 @@ __device__ __forceinline__ size_t tile_off(int row, int quad, int C) {
 // own units [u_begin, u_end), so out-of-range offsets are dropped by the hardware.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kAuxWriteThrough = 16;      // sc1
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t units_rsrc(const float* base, int u_begin, int u_end, int C) {
-    const unsigned long long a = (unsigned long long)(base + (size_t)u_begin * (32 * C));
-    const unsigned long long span = (unsigned long long)(u_end > u_begin ? u_end - u_begin : 0) * (32ull * C * 4);
+// `unit_bytes` = bytes of one 32-row unit of the buffer (32 x C x element size)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t units_rsrc(const void* base, int u_begin, int u_end, int unit_bytes) {
+    const unsigned long long a = (unsigned long long)base + (unsigned long long)u_begin * unit_bytes;
+    const unsigned long long span = (unsigned long long)(u_end > u_begin ? u_end - u_begin : 0) * unit_bytes;
     // plain selects + readfirstlane: the descriptor must be provably wave-uniform or every access becomes a waterfall loop
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)(span > 0xffffffffull ? 0xffffffffull : span));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-// byte offset of (row, quad) relative to the first unit of the descriptor
+// byte offset of (row, quad) of an fp32 tile32 buffer relative to the first unit of the descriptor
 __device__ __forceinline__ int units_off(int row, int quad, int C, int u_begin) {
     return (((row >> 5) - u_begin) * (32 * C) + quad * 128 + (row & 31) * 4) * 4;
 }
-__device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+template <typename V16>      // any 16-byte vector (f32x4, f16x8)
+__device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t r, int byte_off, V16 v) {
+    static_assert(sizeof(V16) == 16, "store_wt moves 16 bytes");
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, kAuxWriteThrough);
 }
 

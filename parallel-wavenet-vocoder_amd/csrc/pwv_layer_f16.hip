@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     };
     if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
     auto no_extra = [](int) {};
-    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(p.x_out[net], u_begin, u_end, 64);      // unused with HEAD
+    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(p.x_out[net], u_begin, u_end, 32 * 64 * 4);      // unused with HEAD
 
     // x[t-d] / x[t] rows of one unit -> registers (clamped addresses, zeros left of the utterance start)
     auto load_x = [&](int unit, float (&xb)[32], float (&xc)[32]) {
@@ -394,12 +394,14 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             gemm16<4, 4, 0, 1, 4>(AS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; },
                                   [&](int s) -> f16x8 { return ol[s]; }, no_extra, [](f16x8(&)[4], f16x8(&)[4]) {});
             if (valid) {
+                const __amdgpu_buffer_rsrc_t skip_rs = units_rsrc(p.skip[net], u_begin, u_end, 32 * 128 * 4);
+                const int soff = units_off(row, h, 128, u_begin);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(srow + (8 * it + 2 * q) * 128) = v;
+                        store_wt(skip_rs, soff + (8 * it + 2 * q) * 512, v);
                     }
             }
         }

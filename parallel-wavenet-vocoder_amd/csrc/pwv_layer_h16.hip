@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
         return u_begin + __builtin_amdgcn_readfirstlane(v);
     };
 
+    const __amdgpu_buffer_rsrc_t out_rs = units_rsrc(xout, u_begin, u_end, 32 * 64 * 2);      // write-through stores, see pwv_layer_common.h
     for (int unit = u_begin + wave; unit < u_end; unit = grab()) {
         int row, rc, n, t;
         bool valid;
@@ -157,11 +158,11 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
         oh[2] = to_h8<16>(o);
         oh[3] = to_h8<24>(o);
 
-        _Float16* orow = xout + xoff(row, h, 64);
+        const int ooff = (int)((xoff(row, h, 64) - (size_t)u_begin * (32 * 64)) * 2);      // bytes from this workgroup's first unit
         if constexpr (GATED) {
             if (valid) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8*>(orow + s * 512) = oh[s];
+                for (int s = 0; s < 4; ++s) store_wt(out_rs, ooff + s * 1024, oh[s]);
             }
         } else {
             // dense 64 -> 64; accumulator starts at x[t] + dense_bias (register r of tile it <-> half q = r&7 of chunk 2it + (r>>3))
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
                 float y[32];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) y[i] = acc2[i >> 4][i & 15];
-                *reinterpret_cast<f16x8*>(orow + 0 * 512) = to_h8<0>(y);
-                *reinterpret_cast<f16x8*>(orow + 1 * 512) = to_h8<8>(y);
-                *reinterpret_cast<f16x8*>(orow + 2 * 512) = to_h8<16>(y);
-                *reinterpret_cast<f16x8*>(orow + 3 * 512) = to_h8<24>(y);
+                store_wt(out_rs, ooff + 0 * 1024, to_h8<0>(y));
+                store_wt(out_rs, ooff + 1 * 1024, to_h8<8>(y));
+                store_wt(out_rs, ooff + 2 * 1024, to_h8<16>(y));
+                store_wt(out_rs, ooff + 3 * 1024, to_h8<24>(y));
             }
         }
     }

@@ -30,6 +30,11 @@
 
 #include <cstdlib>
 
+// cache policy of the strip stores: 0 = plain (the strips are produced and consumed through the XCD's own L2)
+#ifndef PWV_PERSIST_STORE_AUX
+#define PWV_PERSIST_STORE_AUX 0
+#endif
+
 namespace pwv {
 
 constexpr int kSlot = kA1Size + kA2Size;   // floats per LDS half: filter|gate (hi+lo) + dense (hi+lo) = 81,920 B
@@ -545,10 +550,10 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 for (int g = 0; g < 8; ++g) {
                     const int it = g >> 2, q = g & 3;
                     const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                    #ifdef PWV_ABL_NTSTORE
+#ifdef PWV_ABL_NTSTORE
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, 2);
 #else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, PWV_PERSIST_STORE_AUX);
 #endif
                 }
             }
