@@ -266,7 +266,9 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
                 const int mr = rt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                 float v = acc[it][r];
                 if (relu) v = fmaxf(v, 0.f);
-                if (mr < M && n < Nout) y[(size_t)mr * Nout + n] = v;
+                // agent-scope relaxed store = a plain store with `sc1` (write-through): the consumer is the NEXT launch, and lines
+                // that are already clean need no write-back at this kernel's end (see store_wt in pwv_layer_common.h)
+                if (mr < M && n < Nout) __hip_atomic_store(&y[(size_t)mr * Nout + n], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
