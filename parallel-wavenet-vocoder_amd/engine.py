@@ -45,6 +45,9 @@ EVENT_LOG = None
 # of phase and one chain's launch gap / cold start / tail is covered by the other's bulk
 # (measured: 48 vs 55 us per layer pair at 160000 samples).  Otherwise both nets share one launch.
 TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
+# PWV_HOIST_P=0: every flow computes its own frame-rate projections at its start (A/B knob; default: one GEMM for all
+# nets of the forward before the first flow, see project_all)
+HOIST_P = os.environ.get('PWV_HOIST_P', '1') != '0'
 # PWV_FUSE_FIRST=0: materialise the causal layer with the front kernel even where layer 0 could rebuild it (A/B knob)
 FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
 # PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
@@ -472,6 +475,49 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         check(lib.pwv_wavenet_head_f32(ctypes.byref(ha), s), 'pwv_wavenet_head_f32')
 
 
+_bank_cache = {}      # tuple of plan ids -> (plans (kept alive), concatenated proj_w [K, total], proj_b [total], column offsets)
+
+
+def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
+    """The frame-rate projections P of EVERY net of a forward (all flows) as one GEMM: P depends on the mel frames only,
+    not on a flow's input, so none of it has to sit between two flows (per flow that was two small launches plus their
+    cross-stream dependencies on the critical path).  The result is attached to the RepeatedCondition; run_nets picks its
+    nets' column blocks out of it (row stride = all columns).  Nets that cannot use it (not fused-capable, a different
+    arithmetic after the range fallback) simply project for themselves as before."""
+    if not HOIST_P or not isinstance(cond, RepeatedCondition) or not nets:
+        return
+    prec = PRECISIONS[precision or DEFAULT_PRECISION]
+    plans = []
+    for net in nets:
+        if not getattr(net, 'fused_supported', None) or not net.fused_supported(cond):
+            continue
+        if cond.frames.shape[2] != net.condition_channels:
+            continue
+        p = get_plan(net, 'frames', prec)
+        if prec == _lib.PREC_F16X3 and not (p.f16x3_ok and p.x_limit > 0):
+            continue
+        if all(p is not q for q in plans):
+            plans.append(p)
+    if len(plans) < 2:
+        return
+    key = tuple(id(p) for p in plans)
+    hit = _bank_cache.get(key)
+    if hit is None:
+        if len(_bank_cache) >= 8:
+            _bank_cache.clear()
+        offs, total = [], 0
+        for p in plans:
+            offs.append(total)
+            total += p.proj_w.shape[1]
+        hit = (plans, torch.cat([p.proj_w for p in plans], dim=1).contiguous(), torch.cat([p.proj_b for p in plans]).contiguous(), offs)
+        _bank_cache[key] = hit
+    _, w_all, b_all, offs = hit
+    n, frames, c = cond.frames.shape
+    f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames, c)
+    p_all = linear_op(f2d, w_all, b_all, relu=False, precision=precision or DEFAULT_PRECISION)
+    cond.proj_bank = {id(p): p_all[:, o:o + p.proj_w.shape[1]] for p, o in zip(plans, offs)}
+
+
 def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,
              max_workgroups: int = 0) -> List[torch.Tensor]:
     """Evaluate 1 or 2 structurally identical fused-capable WaveNets on the same input/condition.
@@ -564,7 +610,12 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
                and max_workgroups == 0 and _persist_fits(G, rows, L))
     two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
-    if mode == 'frames':
+    row_stride = 128 * L
+    bank = getattr(cond, 'proj_bank', None) if mode == 'frames' else None
+    if bank is not None and all(id(p) in bank for p in plans):
+        projs = [bank[id(p)] for p in plans]          # column blocks of the forward's one projection GEMM (project_all)
+        row_stride = projs[0].stride(0)
+    elif mode == 'frames':
         f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames_per_utt, -1)
         if two:
             # net 0's P on the main stream, net 1's on its own stream: its chain then starts one small GEMM
@@ -579,7 +630,6 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             projs = [linear_op(f2d, p.proj_w, p.proj_b, relu=False, precision=precision or DEFAULT_PRECISION) for p in plans]
     else:
         projs = [p.proj_b.reshape(1, -1) for p in plans]
-    row_stride = 128 * L
 
     # ---- causal layer (modules.py:174-183) ----------------------------------------------------
     R = net0.residual_channels

@@ -73,6 +73,7 @@ class IAFVocoder(object):
                 input = engine._require_cuda_f32(z, 'z')
                 if tuple(input.shape) != (n, self.length, 1):
                     raise ValueError('z must be [%d, %d, 1], got %s' % (n, self.length, tuple(input.shape)))
+            flows = []
             for i in range(hp.model.n_iaf):
                 with variable_scope('iaf{}'.format(i)):
                     kwargs = dict(
@@ -96,8 +97,11 @@ class IAFVocoder(object):
                         scaler = WaveNet(quantization_channels=1, name='scalar', **kwargs)
                         shifter = WaveNet(quantization_channels=1, name='shifter', **kwargs)
                         iaf = LinearIAFLayer(batch_size=hp.train.batch_size, scaler=scaler, shifter=shifter)
-                    input = iaf(input, condition)  # (n, t, h)
-
+                    flows.append(iaf)
+            # the frame-rate projections of every net depend on the mel only: one GEMM for all flows, ahead of the first
+            engine.project_all([net for iaf in flows for net in iaf.nets()], condition, precision=self.precision)
+            for i, iaf in enumerate(flows):
+                input = iaf(input, condition)  # (n, t, h)
                 # normalization (identity at the default hparams), models.py:70
                 input = normalize(input, is_training, hp.model.normalize, name='normalize{}'.format(i), store=store)
         return input

@@ -309,6 +309,9 @@ class LinearIAFLayer(object):
         self.scaler = scaler
         self.shifter = shifter
 
+    def nets(self):
+        return [self.scaler, self.shifter]
+
     def __call__(self, input, condition=None):
         '''
         input = (n, t, h), condition = (n, t, h)
@@ -338,6 +341,9 @@ class SharedIAFLayer(object):
     def __init__(self, batch_size, net):
         self.batch_size = batch_size
         self.net = net
+
+    def nets(self):
+        return [self.net]
 
     def __call__(self, input, condition=None):
         y = self.net(input, condition)                      # [N, T, 2]
