@@ -391,6 +391,32 @@ def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, precisi
     assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_one_projection_gemm_for_all_flows_is_bit_identical(gpu, precision, monkeypatch):
+    """engine.project_all: the frame-rate projections of every net as one GEMM ahead of the first flow -- each column is the
+    same dot product in the same order as in the per-flow GEMMs, so nothing may change (3 flows of different depth, ragged
+    batch); and the nets really read the shared result (row stride = all columns)."""
+    from pwv_amd import engine
+    cfg = O.ModelConfig(dilations=[[1, 2, 4], [4, 1, 8, 2], [2]], n_iaf=3, cond_upsample_method='repeat')
+    weights = O.init_weights(cfg, seed=33)
+    mel, z = O.synthetic_inputs(3, 80 * 5, cfg)
+    seen = []
+    real = engine.linear_op
+
+    def spy(x2d, w, b, relu, precision=None):
+        seen.append(tuple(w.shape))
+        return real(x2d, w, b, relu, precision=precision)
+    monkeypatch.setattr(engine, 'linear_op', spy)
+    monkeypatch.setattr(engine, 'HOIST_P', True)
+    a = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
+    hoisted = [s for s in seen if s[1] == 128 * 2 * (3 + 4 + 1)]
+    assert len(hoisted) == 1 and not [s for s in seen if s[1] in (128 * 3, 128 * 4, 128)], seen
+    monkeypatch.setattr(engine, 'HOIST_P', False)
+    b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
+    assert np.array_equal(a, b)
+    assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
+
+
 def test_plain_c_client_runs(gpu, tmp_path):
     """The C99 client (examples/c_abi_smoke.c) drives pwv_causal_conv_f32 and the tile32 converters with raw
     hipMalloc'd pointers and checks them against loops written in C."""
