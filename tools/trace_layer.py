@@ -64,6 +64,15 @@ for x in range(2):
     sel = wgt[x::8]
     print('   XCD %d: start spread %d ticks, end spread %d ticks, first start -> last end %d ticks' % (
         x, sel[:, 0].max() - sel[:, 0].min(), sel[:, 2].max() - sel[:, 2].min(), sel[:, 2].max() - sel[:, 0].min()))
+# per-XCD view of the workgroup durations (WG b runs on XCD b % 8 under round-robin dispatch) and of the chip-wide end times
+rt_all = full[4096 + 1024:4096 + 1024 + 2 * len(wgt)].reshape(-1, 2)
+for x in range(8):
+    d = dur[x::8]
+    d = d[d > 0.5 * dur.mean()]          # (the last workgroups have no units)
+    e = rt_all[x::8][:len(dur[x::8])]
+    e = e[e[:, 0] > 0]
+    print('   XCD %d: WG duration ticks mean %6d min %6d max %6d (%d WGs); chip-clock lifetime mean %.2f us, last end at +%.2f us' % (
+        x, d.mean(), d.min(), d.max(), len(d), (e[:, 1] - e[:, 0]).mean() / 100.0, (e[:, 1].max() - rt[:, 0].min()) / 100.0))
 t = full[:2048].reshape(2, 8, 8, 16)
 for b in range(2):
     t0 = t[b][t[b] > 0].min()
