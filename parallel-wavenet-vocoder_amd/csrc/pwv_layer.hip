@@ -735,6 +735,14 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     if (per_net < 1) per_net = 1;
     const int nt4 = (int)((rows + 127) / 128), nt8 = (int)((rows + 255) / 256);   // >= 1 unit per wave
     const int g4 = per_net < nt4 ? per_net : nt4, g8 = per_net < nt8 ? per_net : nt8;
+    // the write-through stores address a workgroup's own units with 32-bit byte offsets (units_rsrc / units_off): 16 KB per
+    // unit of the widest buffer (skip accumulators) must stay below 2 GB per workgroup
+    {
+        const int gmin = g4 < g8 ? g4 : g8;
+        PWV_CHECK_ARG(((rows + 31) / 32 + gmin - 1) / gmin < (1 << 17),
+                      "pwv_wavenet_layer_f32: %lld rows on %d workgroups per net: more than 131071 units per workgroup (raise max_workgroups)",
+                      rows, gmin);
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool cond = a->cond != nullptr, gated = a->out_mode == PWV_OUT_GATED;
     PWV_CHECK_ARG(a->out_mode == PWV_OUT_GATED || a->out_mode == PWV_OUT_RESIDUAL, "pwv_wavenet_layer_f32: bad out_mode");
