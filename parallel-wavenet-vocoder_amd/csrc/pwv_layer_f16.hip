@@ -110,7 +110,6 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     (void)tr_unit;
     int unit = u_begin + wave;
     float rxb[32], rxc[32];      // raw rows of the current unit (prefetched during the previous unit's GEMM2)
-    load_x(unit, rxb, rxc);      // in flight while the weights are staged
     if constexpr (FIRST) {
         if (tid < 128) lds[kCF + tid] = p.cfilt[net][tid];
     }
@@ -125,6 +124,14 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #ifdef PWV_TRACE
     if (p.trace && tid == 0) p.trace[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
 #endif
+    // The first unit's rows are requested BEHIND the weights, not ahead of them: vector-memory results return in order per
+    // wave, so rows asked for first (HBM, microseconds under the start-of-kernel burst of all CUs) hold back the weight
+    // transfers (L2 hits) and with them the barrier.  Measured with tools/trace_layer.py: barrier reached after 3.2k instead
+    // of 9.1k cycles, first unit under way after 5.7k instead of 9.3k.  (Keeping the rows in flight ACROSS the barrier
+    // with a partial `s_waitcnt vmcnt(16)` is not worth it: the compiler's wait-count bookkeeping does not credit a partial
+    // wait while loads and LDS-DMA are both outstanding and then puts a vmcnt(0) in front of the first LDS access of
+    // every unit.)
+    load_x(unit, rxb, rxc);
     while (unit < u_end) {
         const int next = HEAD ? unit + WAVES : grab();
         ++tr_unit;

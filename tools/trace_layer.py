@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from pwv_amd import _lib  # noqa: E402
 
 so = '/tmp/libpwv_trace.so'
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-DPWV_TRACE',
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-DPWV_TRACE'] + os.environ.get('PWV_TRACE_FLAGS', '').split() + [
        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'parallel-wavenet-vocoder_amd', 'csrc'), '-o', so] + _lib.CSRC
 subprocess.check_call(cmd)
 _lib.LIB_PATH = so
