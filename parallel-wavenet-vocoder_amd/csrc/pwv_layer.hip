@@ -122,11 +122,11 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
     int* unit_counter = reinterpret_cast<int*>(&lds[HEAD ? 0 : kLds]);      // unused with HEAD
 
     if constexpr (HEAD) {
-        fill_lds<kA1Size / 4, 64 * WAVES>(lds, p.packed[net] + kA1, tid);
-        fill_lds<kASSize / 4, 64 * WAVES>(lds + kHS, p.packed_head[net] + kHAS, tid);
-        fill_lds<kHA1Size / 4, 64 * WAVES>(lds + kH1, p.packed_head[net] + kHA1, tid);
+        fill_lds_dma<kA1Size / 4, WAVES>(lds, p.packed[net] + kA1, wave, lane);
+        fill_lds_dma<kASSize / 4, WAVES>(lds + kHS, p.packed_head[net] + kHAS, wave, lane);
+        fill_lds_dma<kHA1Size / 4, WAVES>(lds + kH1, p.packed_head[net] + kHA1, wave, lane);
     } else {
-        fill_lds<kLds / 4, 64 * WAVES>(lds, p.packed[net], tid);
+        fill_lds_dma<kLds / 4, WAVES>(lds, p.packed[net], wave, lane);
         if (tid == 0) *unit_counter = 0;
         if constexpr (FIRST) {
             if (tid < 128) lds[kCF + tid] = p.cfilt[net][tid];
