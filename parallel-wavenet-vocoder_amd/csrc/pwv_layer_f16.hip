@@ -54,8 +54,8 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         p.trace[4096 + 1024 + blockIdx.x * 2 + 0] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
     }
 #endif
-    // the first WAVES units are handed out statically (wave w takes unit w) so their rows can be
-    // requested before the weights are staged; the counter then starts at WAVES
+    // the first WAVES units are handed out statically (wave w takes unit w: no LDS round trip before the first rows can
+    // be requested); the counter then starts at WAVES
     if constexpr (!HEAD) {
         if (tid == 0) *unit_counter = WAVES;
     }
