@@ -145,7 +145,7 @@ __global__ void pack_proj_kernel(const float* __restrict__ gc_filter, const floa
 }
 
 // Pack-time statistics of one layer's weights for the range analysis of the split-fp16 arithmetic (include/pwv_hip.h,
-// "Range guard"): one workgroup, out[0..7] = max|filter|, max|gate|, max|dense|, max|skip|, max|gc_filter|, max|gc_gate|,
+// "Range guard"): 8 workgroups (one per statistic), out[0..7] = max|filter|, max|gate|, max|dense|, max|skip|, max|gc_filter|, max|gc_gate|,
 // max_out sum_in |dense[in, out]| + max|dense_bias|, max_out sum_in |skip[in, out]| + max|skip_bias|.
 __global__ __launch_bounds__(256) void range_stats_kernel(const float* filter, const float* gate, const float* dense, const float* dense_bias,
                                                           const float* skip, const float* skip_bias, const float* gc_filter,
@@ -177,12 +177,18 @@ __global__ __launch_bounds__(256) void range_stats_kernel(const float* filter, c
         }
         return block_max(m);
     };
-    const float v0 = max_abs(filter, 2 * 64 * 64), v1 = max_abs(gate, 2 * 64 * 64), v2 = max_abs(dense, 64 * 64), v3 = max_abs(skip, 64 * 128);
-    const float v4 = max_abs(gc_filter, C * 64), v5 = max_abs(gc_gate, C * 64);
-    const float v6 = colsum_max(dense, 64, 64) + max_abs(dense_bias, 64), v7 = colsum_max(skip, 64, 128) + max_abs(skip_bias, 128);
-    if (threadIdx.x == 0) {
-        out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3; out[4] = v4; out[5] = v5; out[6] = v6; out[7] = v7;
+    float v = 0.f;      // one workgroup per statistic (blockIdx.x)
+    switch (blockIdx.x) {
+        case 0: v = max_abs(filter, 2 * 64 * 64); break;
+        case 1: v = max_abs(gate, 2 * 64 * 64); break;
+        case 2: v = max_abs(dense, 64 * 64); break;
+        case 3: v = max_abs(skip, 64 * 128); break;
+        case 4: v = max_abs(gc_filter, C * 64); break;
+        case 5: v = max_abs(gc_gate, C * 64); break;
+        case 6: v = colsum_max(dense, 64, 64) + max_abs(dense_bias, 64); break;
+        default: v = colsum_max(skip, 64, 128) + max_abs(skip_bias, 128); break;
     }
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
 static inline unsigned nblocks(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
@@ -242,7 +248,7 @@ int pwv_range_stats_f32(const float* filter, const float* gate, const float* den
                         const float* skip_bias, const float* gc_filter, const float* gc_gate, int C, float* out8, pwv_stream_t stream) {
     PWV_CHECK_ARG(filter && gate && dense && skip && out8, "pwv_range_stats_f32: NULL pointer");
     PWV_CHECK_ARG((gc_filter == nullptr) == (gc_gate == nullptr) && C >= 0, "pwv_range_stats_f32: gc tensors come in pairs");
-    hipLaunchKernelGGL(range_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, filter, gate, dense, dense_bias, skip, skip_bias,
+    hipLaunchKernelGGL(range_stats_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, filter, gate, dense, dense_bias, skip, skip_bias,
                        gc_filter, gc_gate, gc_filter ? C : 0, out8);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
