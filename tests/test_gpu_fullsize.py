@@ -148,3 +148,23 @@ def test_c3_default_model_full_size_vs_oracle(gpu, precision):
     y = model(None, mel_t, is_training=False, z=z_t).cpu().numpy()
     _oracle_prefix(cfg, w, mel, z, y, 8000, precision)
     _oracle_late_window(cfg, w, mel, z, y, 2400, precision, 0)
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_ragged_many_workgroups(gpu, precision):
+    """A length whose last 32-row unit is half empty and whose units do not divide over the workgroups (3 x 100080 samples:
+    9383 units, the last of every utterance 16 rows short of a tile32 block boundary shared with the next utterance): the
+    write-through stores address a workgroup's own units through a bounded descriptor, so the ends of the ranges are where
+    a mistake would show.  Prefix and end of the LAST utterance against the oracle, batched == single bit for bit."""
+    import torch
+    cfg = O.ModelConfig()
+    n, L = 3, 100080
+    model, w, mel, z, mel_t, z_t = _model(gpu, cfg, n, L, precision)
+    y_t = model(None, mel_t, is_training=False, z=z_t)
+    y = y_t.cpu().numpy()
+    _oracle_prefix(cfg, w, mel, z, y, 4000, precision, utts=slice(1, 2))
+    _oracle_late_window(cfg, w, mel, z, y, 2400, precision, n - 1)
+    from pwv_amd.models import IAFVocoder
+    one = IAFVocoder(batch_size=1, length=L, store=model.store, precision=precision)
+    yi = one(None, mel_t[1:2].contiguous(), is_training=False, z=z_t[1:2].contiguous())
+    assert torch.equal(yi[0], y_t[1])
