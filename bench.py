@@ -478,8 +478,8 @@ def main():
                 result['roofline']['limiter'] = ('two stacked limits, neither of them HBM: (1) issue -- every VALU instruction takes 2-2.7 cycles of matrix-pipe '
                                                  'time on a SIMD (tools/probes/coissue.hip, same cycle counts on 8 workgroups at 2.4 GHz), so 120 MFMA + ~700 VALU '
                                                  'per 32-row unit give 44-46 % matrix-pipe busy (profiles/r02_g_sq_counters.md); (2) clock -- rocm-smi reads '
-                                                 '1399-1402 W of the 1400 W package cap with sclk held at ~1.82 of 2.4 GHz during this bench '
-                                                 '(profiles/r02_power_clock.md).  By arithmetic intensity (240 fp16-FLOP/B < 312) the HBM roof is the nominal one '
+                                                 '1380-1400 W of the 1400 W package cap with sclk held at 1.82-1.92 of 2.4 GHz during this bench '
+                                                 '(profiles/r02_power_clock.md, r02_i_power_clock.md).  By arithmetic intensity (240 fp16-FLOP/B < 312) the HBM roof is the nominal one '
                                                  '-- DESIGN.md section 4, K1 item 6 and K1p')
                 result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
                                            'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
