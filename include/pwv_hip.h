@@ -357,24 +357,32 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
  * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation, no per-sample condition,
  * PWV_PREC_F16X3 or PWV_PREC_F32) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
  * (modules.py:138-143) without a kernel boundary, a weight-staging phase and a ramp-up / ramp-down per layer.
- *   x_in[g]  input of the run's first layer, x_out[g] output of its last layer (both full-size tile32 buffers,
- *   N*T rows x 64); layer j of the run reads packed_layers[g] + j*packed_layer_stride and the P columns
- *   proj[g] + 128*j.  Results are bit-identical to n_layers calls of pwv_wavenet_layer_f32.
- * Each of the chip's 8 XCDs works on its own eighth of the rows (recomputing the x[t-d] halo of the later layers), its
- * workgroups hand (layer, unit) tasks to each other through flags in `workspace`; csrc/pwv_stack_persist.hip has the
- * protocol.  The call enqueues a memset of the workspace's control words and one kernel (grid = one workgroup per CU).
- *   pwv_persist_workspace_bytes   size of `workspace` (device memory, 256-byte aligned, contents don't care)
+ *   x_ring[g]  three full-size tile32 buffers (N*T rows x 64) per net, `ring_stride` floats apart (>= pwv_tile32_floats(N*T, 64)).
+ *   Layer j of the run reads buffer (j + 2 + r) % 3 and writes buffer (j + r) % 3, r = ring_rotation: the input of the run is
+ *   in buffer (2 + r) % 3 on entry, its output in buffer (n_layers - 1 + r) % 3 on return; the third buffer holds
+ *   intermediate layers (a stack can be cut into several runs that hand the ring on: r' = (output buffer + 1) % 3).  Layer j reads
+ *   packed_layers[g] + j*packed_layer_stride and the P columns proj[g] + 128*j.
+ *   Results are bit-identical to n_layers calls of pwv_wavenet_layer_f32.
+ * Every workgroup owns the same contiguous rows in every layer and walks layer after layer over them; what it needs of
+ * its neighbours' rows (the x[t-d] look-back) is handed over through per-workgroup progress words in `workspace`;
+ * csrc/pwv_stack_persist.hip has the protocol.  The call enqueues a kernel that zeroes the control words and one kernel
+ * (grid <= one workgroup per CU; max_workgroups > 0 limits it further, e.g. to share the chip with another stream).
+ *   pwv_persist_workspace_bytes   size of `workspace` (device memory, 256-byte aligned, contents don't care) for the shape in
+ *                                 `args` (G, N, T, n_layers, dilations, max_workgroups, min_units_per_workgroup are read);
+ *                                 0 = this shape cannot run as a persistent launch (pwv_last_error says why): use the
+ *                                 per-layer launches
  *   pwv_persist_status(&p)        process-wide sticky int32 in pinned host memory: 0, or != 0 once a launch gave up
- *                                 (a workgroup placement it was not planned for, or a poll that ran into its bound);
- *                                 the outputs of that launch are then invalid and the caller uses the per-layer path.
- * Use it for N*T large enough that every XCD has more units than waves (N*T >= 2^16 at G = 2).
+ *                                 (a poll that ran into its bound: the workgroups were not all resident, e.g. because
+ *                                 another process held CUs); the outputs of that launch are then invalid and the caller
+ *                                 uses the per-layer path.
  * ------------------------------------------------------------------------------------- */
 typedef struct pwv_persist_args {
     int G;
     int n_layers;                                 /* 2..32 layers in this launch */
     const int* dilations;                         /* HOST array [n_layers] */
-    const float* x_in[PWV_MAX_NETS];
-    float* x_out[PWV_MAX_NETS];
+    float* x_ring[PWV_MAX_NETS];
+    size_t ring_stride;                           /* floats between two of a net's three buffers */
+    int ring_rotation;                            /* 0, 1 or 2 */
     const float* packed_layers[PWV_MAX_NETS];     /* the run's first layer */
     size_t packed_layer_stride;
     const float* proj[PWV_MAX_NETS];              /* the run's first layer's columns */
@@ -384,9 +392,11 @@ typedef struct pwv_persist_args {
     void* workspace;
     size_t workspace_bytes;
     int precision;                                /* PWV_PREC_F16X3 or PWV_PREC_F32 (packed_layers packed accordingly) */
+    int max_workgroups;                           /* 0 = one per CU */
+    int min_units_per_workgroup;                  /* short inputs: use fewer workgroups rather than ranges below this (0 = 4) */
 } pwv_persist_args;
 
-size_t pwv_persist_workspace_bytes(int G, int N, int T, int n_layers, const int* dilations);
+size_t pwv_persist_workspace_bytes(const pwv_persist_args* args);
 int pwv_persist_status(int** status);
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream);
 

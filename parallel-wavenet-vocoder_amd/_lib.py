@@ -45,6 +45,12 @@ class PwvRangeError(PwvError):
     its result is not trustworthy; rerun with precision='f32'."""
 
 
+class PwvPersistError(PwvError):
+    """A persistent stack launch gave up (csrc/pwv_stack_persist.hip: a bounded poll ran out, e.g. because another process
+    held CUs and its workgroups were not all resident): its outputs are invalid.  The per-layer path is used from then on;
+    rerun the forward."""
+
+
 class LayerArgs(Structure):
     _fields_ = [
         ('G', c_int),
@@ -121,8 +127,9 @@ class PersistArgs(Structure):
         ('G', c_int),
         ('n_layers', c_int),
         ('dilations', POINTER(c_int)),
-        ('x_in', c_void_p * PWV_MAX_NETS),
-        ('x_out', c_void_p * PWV_MAX_NETS),
+        ('x_ring', c_void_p * PWV_MAX_NETS),
+        ('ring_stride', c_size_t),
+        ('ring_rotation', c_int),
         ('packed_layers', c_void_p * PWV_MAX_NETS),
         ('packed_layer_stride', c_size_t),
         ('proj', c_void_p * PWV_MAX_NETS),
@@ -132,6 +139,8 @@ class PersistArgs(Structure):
         ('workspace', c_void_p),
         ('workspace_bytes', c_size_t),
         ('precision', c_int),
+        ('max_workgroups', c_int),
+        ('min_units_per_workgroup', c_int),
     ]
 
 
@@ -198,7 +207,7 @@ def _declare(lib):
     lib.pwv_add_f32.argtypes = [f32p, f32p, f32p, c_int64, c_void_p]
     lib.pwv_gate_f32.argtypes = [f32p, f32p, f32p, c_int64, c_void_p]
     lib.pwv_persist_workspace_bytes.restype = c_size_t
-    lib.pwv_persist_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int)]
+    lib.pwv_persist_workspace_bytes.argtypes = [POINTER(PersistArgs)]
     lib.pwv_persist_status.argtypes = [POINTER(c_void_p)]
     lib.pwv_wavenet_stack_persist_f32.argtypes = [POINTER(PersistArgs), c_void_p]
     lib.pwv_range_stats_f32.argtypes = [f32p] * 8 + [c_int, f32p, c_void_p]

@@ -1,82 +1,81 @@
-// Persistent dataflow kernel for a run of consecutive gated-residual layers (modules.py:185-259) of one or two nets,
-// split-fp16 arithmetic -- ONE launch instead of one launch per layer.
+// Persistent kernel for a run of consecutive gated-residual layers (modules.py:185-259, the loop at modules.py:138-143)
+// of one or two nets -- ONE launch instead of one launch per layer, split-fp16 or exact-fp32 arithmetic.
 //
-// Why: a per-layer launch of layer_f16x3_kernel spends ~60 % of its life in steady state; the rest is weight staging
-// (82 KB per workgroup, serial at the start), the ragged start / finish of the wave population and the ~7 us between
-// dependent kernels ("What bounds it").  Here the waves never stop between layers:
+// Why: a per-layer launch of layer_f16x3_kernel pays, besides its steady state, a weight-staging prologue (1.7 us), the
+// first rows' latency (1.3 us), the spread of its workgroups' end times (~8 %: every workgroup waits for the slowest at
+// EVERY layer) and the gap to the dependent launch (1.5 us): ~20 % of a 46 us launch.
 //
-//  * The chip is treated as 8 independent XCDs.  XCD x owns 1/8 of the rows (a contiguous time range) of every net and
-//    recomputes, per layer, the few units left of its range that its later layers look back to (the x[t-d] halo; whole
-//    32-row units accumulated from the last layer backwards, so each layer's inputs are contained in what the layer
-//    before produced).  No data ever crosses an XCD boundary inside the launch: the L2 an XCD's workgroups share is
-//    the only coherence point needed.  Intermediate layers live in per-XCD "strips" (3 rotating buffers); only the
-//    launch's last layer writes the ordinary full-size buffer.
-//  * Inside an XCD the (layer, unit) tasks of a net are dealt round-robin, layer-major, to the waves of its workgroups:
-//    wave w takes tasks w, w + NW, ...  Every dependency of a task is (almost) a whole layer-sweep old, so the per-unit
-//    progress flags (global memory, L2-served, agent-scope relaxed atomics) are satisfied on the first poll in steady
-//    state; they make the schedule correct, not fast.  RAW: task (j, u) needs units u, (32u-d)>>5, (32u+31-d)>>5 of layer
-//    j-1 complete.  WAR: its output replaces layer j-3's in the strip ring, whose readers are layer j-2's tasks of the
-//    units u+floor(d'/32), u+ceil(d'/32).
-//  * Producer: plain 16-byte stores (they stay in the XCD's L2) -> the wave's next natural `s_waitcnt vmcnt(0)` -> flag.
-//    Consumer: flag poll -> `sc1` 16-byte loads (bypass the CU's vector L1, which other CUs' stores never refresh; served
-//    by the shared L2).  Workgroups find their XCD with s_getreg(HW_REG_XCC_ID) and take a slot from a per-XCD counter, so
-//    nothing depends on the dispatcher's block -> XCD placement; every spin is bounded and reports through a sticky
-//    status word in pinned host memory (the host then uses the per-layer path).
-//  * Weights: both LDS halves (2 x 80 KB = all of the CU's LDS) hold the packed filter|gate + dense matrices of layers j
-//    and j+1; when the last of a workgroup's 8 waves leaves layer j (a counter in global memory -- LDS is full), that wave
-//    refills the half with layer j+2 by LDS-DMA while the others already compute layer j+1.  The dense bias (64 floats)
-//    is read from global memory per unit.
+// Round 3 design -- STATIC ownership (the round-2 kernel dealt (layer, unit) tasks out of per-XCD pools with global
+// atomics, recomputed the x[t-d] halo per XCD and was 3 % slower than the launches it replaced):
+//
+//  * Workgroup w of a net owns the units [u_begin, u_end) -- the SAME contiguous rows in every layer, what the per-layer
+//    kernel gives it per launch -- and walks layer after layer over them.  Nothing is recomputed.  Its 8 waves take
+//    (layer, unit) tasks from ONE LDS counter, layer-major, units in DESCENDING order; a wave that finishes its last unit
+//    of layer j takes a unit of layer j+1 at once: no barrier between layers, inside the workgroup or across the grid.
+//  * Dependencies are tracked, not assumed.  RAW: task (j, u) reads layer j-1's units u, u - ceil(d/32), (32u+31-d)>>5.
+//    WAR: it overwrites ring slot j % 3, last read by layer j-2's tasks of the units u, u + floor(d'/32), u + ceil(d'/32).
+//    Inside the own range: one byte per unit in LDS ("layers completed").  Across workgroups: one progress word per
+//    workgroup in global memory ("layers completed for ALL my units"), needed only by the bottom units (left neighbour's
+//    top rows) and the top units (right neighbour's reads of the slot being overwritten).  With descending order and a
+//    ring of THREE buffers both cross-workgroup dependencies are a whole layer old when they are needed: a workgroup is
+//    coupled to its neighbours only loosely, so the per-layer end-time noise averages out instead of adding up.
+//  * Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16 R1): every x load
+//    is `sc1` (L2-served, never the CU's L1, which other CUs' stores do not refresh); units a neighbour reads are stored
+//    write-through (`sc1`); every wave drains `vmcnt(0)` before it publishes; the progress word is an agent-scope store
+//    by the LAST wave to leave the layer (each wave counts itself out only after its drain).
+//  * Weights: LDS holds layers j and j+1 (2 x 79 KB + 2 x 256 B of dense bias); the last wave to leave layer j refills
+//    that slot with layer j+2 by LDS-DMA and announces it at its next drain.  The 2 KB that buys the control state come
+//    from the LAST 1 KB fragment of each layer's dense matrix, which every unit reads from global memory (one 16-byte load
+//    per lane, an L1 / L2 hit) instead.
+//  * Every spin is bounded and reports through a sticky status word in pinned host memory; the host then reruns on the
+//    per-layer path.  All workgroups must be resident (grid <= CUs, one workgroup per CU by its LDS size).
+// Results are bit-identical to the per-layer launches (same per-unit arithmetic): tests/test_gpu_persist.py.
 #include "pwv_f16x3.h"
 
 #include <cstdlib>
 
-// cache policy of the strip stores: 0 = plain (the strips are produced and consumed through the XCD's own L2)
+// cache policy of the stores of units no other workgroup reads (0 = plain: produced and consumed through one CU's L2)
 #ifndef PWV_PERSIST_STORE_AUX
 #define PWV_PERSIST_STORE_AUX 0
 #endif
 
 namespace pwv {
 
-constexpr int kSlot = kA1Size + kA2Size;   // floats per LDS half: filter|gate (hi+lo) + dense (hi+lo) = 81,920 B
-#ifndef PWV_RING
-#define PWV_RING 2
-#endif
-constexpr int kRing = PWV_RING;            // strip buffers per (net, XCD)
+constexpr int kSlotFull = kA1Size + kA2Size;   // floats of a layer's matrices: filter|gate (hi+lo) + dense (hi+lo) = 81,920 B
+constexpr int kSlot = kSlotFull - 256;         // held in LDS: everything but the last 1 KB fragment of the dense matrix
+constexpr int kBiasF = 2 * kSlot;              // [2 slots][64] dense bias
+constexpr int kCtlF = kBiasF + 128;            // control ints: [0] task counter, [1] abort, [2..3] flag bytes, [8 + j] waves that left layer j
+constexpr int kCtlInts = 40;
+constexpr int kLdsFloats = 40960;              // all 160 KB of the CU
+constexpr int kDoneB = (kCtlF + kCtlInts) * 4;             // byte offset of the per-unit "layers completed" bytes
+constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 1376 units per workgroup
+constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
+constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
 constexpr int kMaxPLayers = 32;
-constexpr int kSpinLimit = 1 << 17;        // polls before a wave gives up (~0.1-0.3 s)
-constexpr int kCtlWg = 64;                 // ints of control state per workgroup: [p] newest layer resident in LDS half p, [2 + j] done[j]
-constexpr int kCtlXcd = 64;                // ints of control state per XCD (own cache lines): [0] workgroup slot counter, [16 + 16 g] task counter of net g
-constexpr int kCtlHead = 8 * kCtlXcd;      // ints in front of the per-workgroup blocks
+constexpr int kSpinLimit = 1 << 16;            // polls before a wave gives up (tens of ms)
+constexpr int kProgStride = 32;                // ints between two workgroups' progress words (own 128-byte lines)
+constexpr int kMaxReachWgs = 60;               // neighbours polled by one wave instruction
 
 struct PersistParams {
-    const float* x_in[PWV_MAX_NETS];       // full-size tile32: input of this launch's first layer
-    float* x_out[PWV_MAX_NETS];            // full-size tile32: output of this launch's last layer
+    float* ring[PWV_MAX_NETS];             // three full-size tile32 buffers, `ring_stride` floats apart; layer j reads buffer (j + 2 + rot) % 3, writes (j + rot) % 3
+    long long ring_stride;
     const float* packed[PWV_MAX_NETS];     // packed layers of this launch, `packed_stride` floats apart
     const float* proj[PWV_MAX_NETS];       // P rows; this launch's first layer at column 0, layer j at 128 j
-    float* strips[PWV_MAX_NETS];           // [8 XCD][kRing][strip_units * 2048 floats]
-    int* flags[PWV_MAX_NETS];              // [8 XCD][strip_units] layers completed per unit
-    int* ctl;
+    int* prog;                             // [G][nwg] progress words, kProgStride ints apart, zeroed per launch
     int* status;                           // pinned host word: != 0 after a give-up
     long long packed_stride;
     int proj_row_stride;
-    int G, N, T, n_layers, units, upx, strip_units, wpx;     // wpx: workgroups per (XCD, net)
+    int G, N, T, n_layers, units, per_wg, nwg, last_wg, reach_wgs, xcd_map, rot;
     int cond_hop, cond_offset, cond_frames;
     unsigned T_magic, T_shift, hop_magic, hop_shift;
     int dil[kMaxPLayers];
-    int hu[kMaxPLayers];                   // halo units of layer j: hu[last] = 0, hu[j-1] = hu[j] + ceil(dil[j] / 32)
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
 };
 
-
-// -DPWV_PTRACE: every wave accumulates s_memtime cycles per phase: [0] whole loop, [1] TOP wait (vmcnt(0)), [2] RAW spins,
-// [3] WAR spins, [4] leave_layer, [5] weight-ready spins, [6] units, [7] RAW spins taken, [8] first task at, [9] last task done at
+// -DPWV_PTRACE: every wave accumulates s_memtime cycles: [0] whole loop, [1] drain at the top, [2] RAW spins, [3] WAR spins,
+// [4] settle (publish / leave / refill), [5] units, [6] tasks that were not prefetched, [7] first task at, [8] last task done at
 #ifdef PWV_PTRACE
-#define PT_DECL long long pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = 0; (void)pt_t; long long pt_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_p = 0; long long pt_top[6] = {0, 0, 0, 0, 0, 0}; long long pt_q = 0;
-#define PT_TOP0() pt_q = __builtin_amdgcn_s_memtime()
-#define PT_TOP(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); pt_top[k] += n_ - pt_q; pt_q = n_; } while (0)
-// phase stamps: pt_ph[k] accumulates the cycles between PT_PHASE(k-1) and PT_PHASE(k) (PT_PHASE0 opens an iteration)
-#define PT_PHASE0() pt_p = __builtin_amdgcn_s_memtime()
-#define PT_PHASE(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); pt_ph[k] += n_ - pt_p; pt_p = n_; } while (0)
+#define PT_DECL long long pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = 0; (void)pt_t;
 #define PT_BEGIN() pt_t = __builtin_amdgcn_s_memtime()
 #define PT_END(k) pt_acc[k] += __builtin_amdgcn_s_memtime() - pt_t
 #define PT_ADD(k, v) pt_acc[k] += (v)
@@ -85,138 +84,155 @@ struct PersistParams {
 #define PT_BEGIN() do {} while (0)
 #define PT_END(k) do {} while (0)
 #define PT_ADD(k, v) do {} while (0)
-#define PT_PHASE0() do {} while (0)
-#define PT_PHASE(k) do {} while (0)
-#define PT_TOP0() do {} while (0)
-#define PT_TOP(k) do {} while (0)
 #endif
 
-__device__ __forceinline__ int ld_word(const int* p) {
-    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_word(int* p, int v, int lane) {
-    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-#ifdef PWV_PTRACE
-static __device__ long long* g_diag_base = nullptr;
-#define g_diag (g_diag_base ? g_diag_base + (size_t)(2048 + blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 : nullptr)
-#endif
-__device__ __forceinline__ bool spin_ge(const int* p, int need, int* status, int code, int lane) {
-    for (int k = 0; k < kSpinLimit; ++k) {
-        if (ld_word(p) >= need) return true;
-        __builtin_amdgcn_s_sleep(8);
+// dependencies of one task as (LDS byte address, required value) pairs, wave-uniform:
+// [0] own x[t] rows, [1] [2] x[t-d] rows, [3] this layer's weights resident (RAW side); [4] [5] readers of the slot it overwrites (WAR)
+// Kept as ONE VGPR (lane k holds pair k packed as need << 20 | address) plus what the neighbours' progress must reach.
+struct Deps { int v; int needL, needR; };
+constexpr unsigned kRawMask = 0xFu, kWarMask = 0x30u;
+
+// GEMM2 (dense, K = 64) with the fragment source as a functor: the persistent kernel takes the last fragment from a register
+template <typename FR, typename BH, typename BL, typename EF>
+__device__ __forceinline__ void gemm16_dense(FR&& fr, f32x16 (&acc)[2], f16x8 (&ah)[4], f16x8 (&al)[4], BH&& bh, BL&& bl, EF&& extra) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f16x8 nh[2] = {ah[0], ah[1]};
+        f16x8 nl[2] = {al[0], al[1]};
+        if (s + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                nh[i] = fr(0, i, s + 1);
+                nl[i] = fr(1, i, s + 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 b_h = bh(s);
+        const f16x8 b_l = bl(s);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b_h, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b_l, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b_h, acc[i], 0, 0, 0);
+        extra(s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = nh[i];
+            al[i] = nl[i];
+        }
     }
-    if (lane == 0) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef PWV_PTRACE
-    if (lane == 0 && g_diag) { g_diag[0] = code; g_diag[1] = need; g_diag[2] = ld_word(p); g_diag[3] = (long long)p; }
-#endif
-    return false;
+}
+
+// the same for the exact-fp32 arithmetic: 8 groups of (2 row tiles x 4 k-steps)
+template <typename FR, typename BF, typename EF>
+__device__ __forceinline__ void gemm_groups_dense(FR&& fr, f32x16 (&acc)[2], f32x4 (&a)[4], BF&& bval, EF&& extra) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        f32x4 n[2] = {a[0], a[1]};
+        if (g + 1 < 8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) n[i] = fr(i, g + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float b = bval(g * 4 + e);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b, acc[i], 0, 0, 0);
+        }
+        extra(g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = n[i];
+    }
 }
 
 template <bool F32>
 __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * kSlot];
-#ifdef PWV_PTRACE
-    const long long pt_entry_rt = __builtin_amdgcn_s_memrealtime();      // 100 MHz, chip-wide
-    g_diag_base = p.trace;
-#endif
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
-    // ---- which XCD am I on, and which of its workgroups -------------------------------------------------------
-    unsigned xcc_reg;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_reg));
-    const int xcc = __builtin_amdgcn_readfirstlane((int)(xcc_reg & 7u));     // (tells the compiler it is wave-uniform)
-    int* lds_i = reinterpret_cast<int*>(lds);
-    if (tid == 0) lds_i[0] = __hip_atomic_fetch_add(&p.ctl[xcc * kCtlXcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int slot = __builtin_amdgcn_readfirstlane(lds_i[0]);
-    __syncthreads();
-    // The dispatcher usually puts gridDim / 8 workgroups on every XCD, but it is free not to (CUs still held by the previous
-    // kernel's tail, a concurrent stream): however many arrive here, they alternate between the nets and share the XCD's
-    // tasks dynamically.  What must hold is that every net has at least one workgroup on every XCD: the exit census checks it.
-    const int net = slot % p.G;
-    const int wgi = slot / p.G;
-    int* wgctl = p.ctl + kCtlHead + blockIdx.x * kCtlWg;
-    int* task_ctr = p.ctl + xcc * kCtlXcd + 16 + 16 * net;     // next unclaimed task of this (XCD, net)
-    const int w = wgi * 8 + wave;
+    // block -> (net, range).  Observed, for speed only: block b runs on XCD b % 8 -- consecutive ranges of a net go to
+    // blocks of one XCD, so most neighbour traffic stays inside one L2.  Nothing depends on it.
+    int net, w;
+    if (p.xcd_map) {
+        const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+        net = s % p.G;
+        w = x * (p.nwg >> 3) + s / p.G;
+    } else {
+        net = blockIdx.x % p.G;
+        w = blockIdx.x / p.G;
+    }
+    const int rows = p.N * p.T;
+    const int u_begin = w * p.per_wg;
+    const int u_end = u_begin + p.per_wg < p.units ? u_begin + p.per_wg : p.units;
+    const int n = u_end - u_begin;
+    if (n <= 0) return;      // owns nothing; nobody waits for it (the neighbour sets stop at the last owning workgroup)
     const int L = p.n_layers;
-    // the per-layer tables live in two VGPRs (lane j holds entry j) and are read with v_readlane: a dynamically indexed
-    // kernel argument is a scalar LOAD plus a wait each time, and the task bookkeeping at the top of every unit needs ~10
-    const int v_dil = p.dil[lane & (kMaxPLayers - 1)], v_hu = p.hu[lane & (kMaxPLayers - 1)];
-    auto dil_of = [&](int j) -> int { return __builtin_amdgcn_readlane(v_dil, j); };
-    auto hu_of = [&](int j) -> int { return __builtin_amdgcn_readlane(v_hu, j); };
+    const int wl = w - p.reach_wgs > 0 ? w - p.reach_wgs : 0;
+    const int nL = w - wl;
+    const int wr = w + p.reach_wgs < p.last_wg ? w + p.reach_wgs : p.last_wg;
+    const int nR = wr - w;
+
+    int* ctl = reinterpret_cast<int*>(lds + kCtlF);
+    volatile unsigned char* lb = reinterpret_cast<volatile unsigned char*>(lds);
+    int* prog_n = p.prog + (size_t)net * p.nwg * kProgStride;
     const float* const proj_n = p.proj[net];
     const float* const packed_n = p.packed[net];
-    const float* const xin_n = p.x_in[net];
-    float* const xout_n = p.x_out[net];
+    // the per-layer dilations live in one VGPR (lane j holds entry j), read with v_readlane: a dynamically indexed kernel
+    // argument is a scalar LOAD plus a wait each time
+    const int v_dil = p.dil[lane & (kMaxPLayers - 1)];
+    auto dil_of = [&](int j) -> int { return __builtin_amdgcn_readlane(v_dil, j); };
 
-    // ---- weights of the first two layers (LDS-DMA, packed order == LDS order) ---------------------------------------
-    fill_lds_dma<kSlot / 4, 8>(lds, p.packed[net], wave, lane);
-    if (L > 1) fill_lds_dma<kSlot / 4, 8>(lds + kSlot, p.packed[net] + p.packed_stride, wave, lane);
+    // ---- control state, then the weights of the first two layers (LDS-DMA, packed order == LDS order) -------------------
+    for (int k = tid; k < (kLdsFloats - kCtlF); k += 512) ctl[k] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        lb[kSeenLB] = nL ? 0 : 255;
+        lb[kSeenRB] = nR ? 0 : 255;
+        lb[kWreadyB] = 0;
+        lb[kWreadyB + 1] = 1;
+        lb[kTrueB] = 255;
+    }
+    auto fill_slot = [&](int slot, int layer, int first, int step) {
+        const float* src = packed_n + (size_t)layer * p.packed_stride + lane * 4;
+        float* dst = lds + slot * kSlot;
+#pragma clang loop unroll(disable)
+        for (int c = first; c < kSlot / 256; c += step)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 256), (lptr_t)(dst + c * 256), 16, 0, 0);
+        if (first == 0 && lane < 16)      // dense bias [2 h][32]
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + kSlotFull), (lptr_t)(lds + kBiasF + slot * 64), 16, 0, 0);
+    };
+    fill_slot(0, 0, wave, 8);
+    if (L > 1) fill_slot(1, 1, wave, 8);
     __syncthreads();
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-    // ---- this XCD's share ----------------------------------------------------------------------------------------
-    const int rows = p.N * p.T;
-    const int own_lo = xcc * p.upx;
-    const int hi = own_lo + p.upx < p.units ? own_lo + p.upx : p.units;
-    // exit census: the last workgroup of the grid to get here checks that every XCD that owns rows had >= G workgroups
-    auto census = [&]() {
-        __syncthreads();
-        if (tid != 0) return;
-        const int done_wgs = __hip_atomic_fetch_add(&p.ctl[kCtlXcd - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done_wgs != (int)gridDim.x - 1) return;
-        for (int x = 0; x < 8; ++x)
-            if (x * p.upx < p.units && __hip_atomic_load(&p.ctl[x * kCtlXcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.G)
-                __hip_atomic_store(p.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    if (own_lo >= hi) { census(); return; }
-    const int strip_u0 = own_lo - hu_of(0);                        // unit held by strip position 0 (may be negative)
-    int* flags = p.flags[net] + (size_t)xcc * p.strip_units - strip_u0;      // indexed by GLOBAL unit
-    float* strip_base = p.strips[net] + (size_t)xcc * kRing * p.strip_units * 2048;
-    const unsigned strip_bytes = (unsigned)p.strip_units * 8192u;
-    const unsigned full_bytes = (unsigned)(((long long)rows + 31) / 32) * 8192u;
-
-    auto lo_of = [&](int j) -> int { const int v = own_lo - hu_of(j); return v > 0 ? v : 0; };
-    // task index -> (layer, unit); pure function of i (round-robin, layer-major)
-    auto locate = [&](int i, int& j, int& base) -> int {
-        while (j < L && i >= base + (hi - lo_of(j))) { base += hi - lo_of(j); ++j; }
-        return j < L ? lo_of(j) + (i - base) : -1;
-    };
-    // buffers of layer j: input = full-size x_in (first layer) or strip ring (j-1) % kRing; output likewise.
-    // (plain selects + readfirstlane: the descriptor must be provably wave-uniform or every buffer access becomes a
-    // waterfall loop)
-    auto make_rsrc = [&](const float* base, unsigned bytes) -> __amdgpu_buffer_rsrc_t {
+    const unsigned full_bytes = (unsigned)p.units * 8192u;
+    auto make_rsrc = [&](const float* base) -> __amdgpu_buffer_rsrc_t {
         const unsigned long long a = (unsigned long long)base;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, __builtin_amdgcn_readfirstlane(full_bytes), 0x00020000);
     };
-    auto in_rsrc = [&](int j, int& shift) -> __amdgpu_buffer_rsrc_t {
-        const bool first = j == 0;
-        const int slotj = first ? 0 : (j - 1) % kRing;
-        shift = first ? 0 : 32 * strip_u0;
-        return make_rsrc(first ? xin_n : strip_base + (size_t)slotj * p.strip_units * 2048, first ? full_bytes : strip_bytes);
-    };
-    auto out_rsrc = [&](int j, int& shift) -> __amdgpu_buffer_rsrc_t {
-        const bool last = j == L - 1;
-        shift = last ? 0 : 32 * strip_u0;
-        return make_rsrc(last ? xout_n : strip_base + (size_t)(j % kRing) * p.strip_units * 2048, last ? full_bytes : strip_bytes);
-    };
-    // byte offset of lane (row, h)'s first 16-byte chunk inside a tile32 buffer whose row 0 is global row `shift`
-    auto toff = [&](int row, int shift) -> int { const int r = row - shift; return ((r >> 5) * 2048 + h * 128 + (r & 31) * 4) * 4; };
+    float* const ring_n = p.ring[net];
+    auto ring_of = [&](int s) -> float* { return ring_n + (size_t)s * p.ring_stride; };
+    auto mod3 = [](int v) -> int { return v % 3; };
+    auto toff = [&](int row) -> int { return ((row >> 5) * 2048 + h * 128 + (row & 31) * 4) * 4; };
 
     // x[t-d] / x[t] rows of one unit -> registers through sc1 loads (L2-served, never the CU's L1)
     auto load_x = [&](int j, int unit, float (&xb)[32], float (&xc)[32]) {
-        int row, rc, n, t, shift;
+        int row, rc, nn, t;
         bool valid;
-        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
-        const __amdgpu_buffer_rsrc_t r = in_rsrc(j, shift);
+        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(ring_of(mod3(j + 2 + p.rot)));
         const int d = dil_of(j);
         const bool has_prev = t >= d;
-        const int oc = toff(rc, shift), ob = toff(has_prev ? rc - d : rc, shift);
+        const int oc = toff(rc), ob = toff(has_prev ? rc - d : rc);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, oc + g * 1024, 0, 16));
@@ -231,180 +247,187 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 for (int e = 0; e < 4; ++e) xb[4 * g + e] = keep ? v[e] : 0.f;
             }
         };
-#ifdef PWV_ABL_NOXB
-#pragma unroll
-        for (int k = 0; k < 32; ++k) xb[k] = xc[k];
-#else
         if (__all(has_prev)) load_b(true);      // wave-uniform fast path: no select behind the loads, they stay in flight
         else load_b(has_prev);
-#endif
     };
 
-    // flags a task waits for.  RAW (j >= 1): units u, (32u-d)>>5, (32u+31-d)>>5 have completed layer j-1 (count >= j).
-    // WAR (kRing <= j < L-1): the readers of the ring slot it overwrites -- layer j-2's tasks of the units
-    // u+floor(d'/32), u+ceil(d'/32), d' = dil[j-2], where they exist -- are done (count >= j-1).
-    struct Deps { int ra, rb, rc, raw_need, wa, wb, war_need; };      // flag indices (global units) and required counts
+    // ---- dependencies ------------------------------------------------------------------------------------------------
     auto deps_of = [&](int j, int u) -> Deps {
         Deps q;
         const int d = dil_of(j);
-        const int ua = (32 * u - d) >> 5, ub = (32 * u + 31 - d) >> 5;
-        q.ra = u; q.rb = ua < 0 ? u : ua; q.rc = ub < 0 ? u : ub;
-        q.raw_need = j;                                   // j == 0: always satisfied (flags start at 0)
-        // the ring slot it overwrites held layer j - kRing's output, read by layer j - kRing + 1's tasks
-        q.war_need = (j >= kRing && j < L - 1) ? j - kRing + 2 : 0;
-        const int d2 = dil_of(j >= kRing - 1 ? j - kRing + 1 : 0);
-        const int wa = u + (d2 >> 5), wb = u + ((d2 + 31) >> 5);
-        q.wa = wa > hi - 1 ? u : wa; q.wb = wb > hi - 1 ? u : wb;
+        const int ua = u - ((d + 31) >> 5), ub = (32 * u + 31 - d) >> 5;
+        q.needL = 0;
+        q.needR = 0;
+        q.v = kTrueB;                     // (need 0 at the always-255 byte: satisfied)
+        auto put = [&](int k, int addr, int need) { q.v = lane == k ? ((need << 20) | addr) : q.v; };
+        if (j >= 1) put(0, kDoneB + (u - u_begin), j);
+        auto left = [&](int v, int k) {
+            if (j < 1 || v < 0) return;
+            if (v >= u_begin) put(k, kDoneB + (v - u_begin), j);
+            else { put(k, kSeenLB, j); q.needL = j; }
+        };
+        left(ua, 1);
+        left(ub, 2);
+        if (j >= 2) put(3, kWreadyB + (j & 1), j);
+        const int d2 = dil_of(j >= 2 ? j - 2 : 0);
+        auto right = [&](int v, int k) {
+            if (j < 2 || v > p.units - 1) return;
+            if (v < u_end) put(k, kDoneB + (v - u_begin), j - 1);
+            else { put(k, kSeenRB, j - 1); q.needR = j - 1; }
+        };
+        right(u + (d2 >> 5), 4);
+        right(u + ((d2 + 31) >> 5), 5);
         return q;
     };
-    auto wait_raw = [&](const Deps& q) -> bool {
-        return spin_ge(flags + q.ra, q.raw_need, p.status, 4, lane) && spin_ge(flags + q.rb, q.raw_need, p.status, 4, lane) &&
-               spin_ge(flags + q.rc, q.raw_need, p.status, 4, lane);
+    // bit k set: dependency k is NOT yet satisfied (one per-lane byte read of LDS)
+    auto eval = [&](const Deps& q) -> unsigned {
+        const int got = lb[q.v & 0xFFFFF];
+        return (unsigned)__ballot(got < (q.v >> 20));
+    };
+    // neighbours' progress words -> the cached "seen" byte of that side (only ever raised to a value that was observed)
+    auto poll_issue = [&](int side) -> int {
+        const int cnt = side ? nR : nL, w0 = side ? w + 1 : wl;
+        int v = 1 << 20;
+        if (lane < cnt) v = __hip_atomic_load(prog_n + (size_t)(w0 + lane) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto poll_finish = [&](int side, int v, int need) {
+        if (__ballot(v < need) == 0 && lane == 0) lb[side ? kSeenRB : kSeenLB] = (unsigned char)need;
     };
 
-    // Before a wave waits for anybody it publishes everything it owes: the flag of the unit it has just stored and a
-    // weight refill it has issued.  (Claims can run more than a layer ahead when an XCD has few units per wave; without this
-    // a wave could wait for weights whose refill it has itself not announced, or for siblings that wait for its flag.)
+    // Before a wave waits for anybody it publishes everything it owes: the unit it has just stored and a weight refill it
+    // has issued (both become true at a vmcnt(0)).
     int prev_u = -1, prev_j = 0;
-    int dma_pending = -1;          // layer whose LDS-DMA this wave issued and has not yet published
+    int dma_pending = -1;          // layer whose LDS-DMA this wave issued and has not yet announced
+    int left_upto = 0;             // layers [0, left_upto) this wave has counted itself out of
+    bool dead = false;
     auto flush_owed = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (prev_u >= 0) { st_word(flags + prev_u, prev_j + 1, lane); prev_u = -1; }
-        if (dma_pending >= 0) { st_word(&wgctl[dma_pending & 1], dma_pending, lane); dma_pending = -1; }
+        if (prev_u >= 0) { if (lane == 0) lb[kDoneB + (prev_u - u_begin)] = (unsigned char)(prev_j + 1); prev_u = -1; }
+        if (dma_pending >= 0) { if (lane == 0) lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
     };
-
-    // leaving layer jj: count this wave out; the LAST of the workgroup's 8 waves refills the LDS half with layer jj + 2
+    // leaving layer jj (called after a drain: this wave's layer-jj stores are complete).  The LAST of the 8 waves publishes
+    // the workgroup's progress and refills the LDS slot with layer jj + 2.
     auto leave_layer = [&](int jj) {
         int old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&wgctl[2 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[8 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (old == 7 && jj + 2 < L) {
-            if (dma_pending >= 0) flush_owed();       // (a wave that is last twice in a row: announce the earlier refill first)
-            // a rolled loop: one running per-lane address (unrolled, the 80 address pairs cost 40 VGPRs at this point)
-            const float* src = packed_n + (size_t)(jj + 2) * p.packed_stride + lane * 4;
-            float* dst = lds + (jj & 1) * kSlot;
-#pragma clang loop unroll(disable)
-            for (int c = 0; c < kSlot / 256; ++c)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 256), (lptr_t)(dst + c * 256), 16, 0, 0);
-            dma_pending = jj + 2;
+        if (old == 7) {
+            if (lane == 0) __hip_atomic_store(prog_n + (size_t)w * kProgStride, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (jj + 2 < L) {
+                if (dma_pending >= 0) flush_owed();       // (last twice in a row: announce the earlier refill first)
+                fill_slot(jj & 1, jj + 2, 0, 1);
+                dma_pending = jj + 2;
+            }
         }
     };
+    // after a drain: publish the previous unit, count this wave out of the layers it has moved past
+    auto settle = [&](int upto) {
+        if (prev_u >= 0) { if (lane == 0) lb[kDoneB + (prev_u - u_begin)] = (unsigned char)(prev_j + 1); prev_u = -1; }
+        if (dma_pending >= 0) { if (lane == 0) lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
+        for (; left_upto < upto; ++left_upto) leave_layer(left_upto);
+    };
+    auto give_up = [&](int code) {
+        if (lane == 0) {
+            __hip_atomic_store(p.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ctl[1] = 1;
+        }
+        dead = true;
+    };
+    auto wait_deps = [&](const Deps& q, unsigned mask, int code) {
+        for (int k = 0; k < kSpinLimit; ++k) {
+            const unsigned bad = eval(q) & mask;
+            if (!bad) return;
+            if (*(volatile int*)&ctl[1]) { dead = true; return; }
+            if ((bad & 0x6u) && q.needL) poll_finish(0, poll_issue(0), q.needL);
+            if ((bad & 0x30u) && q.needR) poll_finish(1, poll_issue(1), q.needR);
+            __builtin_amdgcn_s_sleep(4);
+        }
+        give_up(code);
+    };
 
-    // ---- tasks are claimed dynamically, in the global (layer-major) order, from one counter per (XCD, net): a wave that
-    // runs slower (the low-priority half of a SIMD pair, a CU with a busier memory path) simply takes fewer of them.
-    // Claims are returning atomics issued one iteration before their result is needed.
+    // ---- tasks: index i = layer * n + k, unit = u_end - 1 - k; claimed from the LDS counter one iteration ahead ---------
     auto claim = [&]() -> int {
         int v = 0;
-        if (lane == 0) v = __hip_atomic_fetch_add(task_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) v = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return v;          // lane 0's value; readfirstlane at the point of use
     };
-    int i = __builtin_amdgcn_readfirstlane(claim());
+    auto locate = [&](int i, int& j) -> int {      // j: a layer at or before the task's (tasks are claimed in increasing order)
+        while (j < L && i >= (j + 1) * n) ++j;
+        return j < L ? u_end - 1 - (i - j * n) : -1;
+    };
+    int j = 0;
+    int u = locate(__builtin_amdgcn_readfirstlane(claim()), j);
     int claim_v = claim();                 // the task after that
-    int j = 0, base = 0;
-    int u = locate(i, j, base);
-    bool dead = false;
-    for (int jj = 0; jj < (u >= 0 ? j : L); ++jj) leave_layer(jj);       // layers this wave has no task in
     float rxb[32], rxc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
     bool war_ok = true, need_load = true;       // need_load: the rows of the task in hand were NOT prefetched
-    int cur_wa = 0, cur_wb = 0, cur_wneed = 0;      // WAR flags of the task in hand
     Deps curd{};
     if (u >= 0) {
-        if (j >= 2) { flush_owed(); dead = !spin_ge(&wgctl[j & 1], j, p.status, 3, lane); }
         curd = deps_of(j, u);
-        cur_wa = curd.wa; cur_wb = curd.wb; cur_wneed = curd.war_need;
-        war_ok = cur_wneed == 0;
+        war_ok = (eval(curd) & kWarMask) == 0;
     }
     PT_DECL
 #ifdef PWV_PTRACE
     const long long pt_start = __builtin_amdgcn_s_memtime();
     const long long pt_start_rt = __builtin_amdgcn_s_memrealtime();
-    pt_acc[8] = pt_start;
+    pt_acc[7] = pt_start;
 #endif
 
-#ifdef PWV_ABL_SHIFT
-#pragma unroll
-    for (int k_ = 0; k_ < PWV_ABL_SHIFT; ++k_) asm volatile("s_nop 0");      // code-placement probe: 4 bytes each
-#endif
     while (u >= 0 && !dead) {
-        // ---- TOP: P row, the next task's flags; then everything this wave has in flight has landed ------------------
-        PT_PHASE0();
-        PT_TOP0();
-        int row, rc, n, t;
+        // ---- TOP: P row and the next task's flags are requested; the rows of this unit were prefetched ---------------------
+        int row, rc, nn, t;
         bool valid;
-        unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, n, t);
+        unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
         f32x16 acc[4];
         {
             int prow = 0;
-            if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
+            if (p.cond_hop > 0) prow = nn * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
             const float* pr = proj_n + (size_t)prow * p.proj_row_stride + j * 128 + h * 64;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-#ifdef PWV_ABL_NOP
-                    const f32x4 v = {0.f, 0.f, 0.f, 0.f}; (void)pr;
-#else
                     const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
-#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                 }
         }
-        PT_TOP(0);      // unit_rows + P loads issued
-        int j2 = j, base2 = base;
-        const int i2 = __builtin_amdgcn_readfirstlane(claim_v);      // claimed an iteration ago
-        const int u2 = locate(i2, j2, base2);
+        int j2 = j;
+        const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);      // claimed an iteration ago
         Deps nxt{};
-        int f_ra = 0, f_rb = 0, f_rc = 0, f_wa = 0, f_wb = 0, f_ld = 0;
-        if (u2 >= 0) nxt = deps_of(j2, u2);
-#ifndef PWV_ABL_NOFLAGS
+        unsigned bad2 = ~0u;
+        int pvL = 0, pvR = 0;
+        bool polledL = false, polledR = false;
         if (u2 >= 0) {
-            f_ra = __hip_atomic_load(flags + nxt.ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f_rb = __hip_atomic_load(flags + nxt.rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f_rc = __hip_atomic_load(flags + nxt.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f_wa = __hip_atomic_load(flags + nxt.wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f_wb = __hip_atomic_load(flags + nxt.wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f_ld = __hip_atomic_load(&wgctl[j2 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nxt = deps_of(j2, u2);
+            bad2 = eval(nxt);
+            // a neighbour's progress is behind what the next task needs, as far as this workgroup has looked: look again
+            polledL = (bad2 & 0x6u) && nxt.needL;
+            polledR = (bad2 & 0x30u) && nxt.needR;
+            if (polledL) pvL = poll_issue(0);
+            if (polledR) pvR = poll_issue(1);
         }
-#else
-        f_ra = f_rb = f_rc = f_wa = f_wb = f_ld = 1 << 20;
-#endif
-        PT_TOP(1);      // claim read, locate, deps, flag loads issued
-        PT_BEGIN();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PT_END(1);
-        PT_TOP(2);      // the wait
-        PT_ADD(6, 1);
-        // the previous unit's stores have reached the L2 (and a refill this wave issued has landed): publish
-        if (prev_u >= 0) { st_word(flags + prev_u, prev_j + 1, lane); prev_u = -1; }     // (once: a later re-publish would LOWER a count)
-        if (dma_pending >= 0) { st_word(&wgctl[dma_pending & 1], dma_pending, lane); dma_pending = -1; }
-        if (u2 >= 0) claim_v = claim();
         if (need_load) {
-            // rows not prefetched (first task, or their producers were not done when the previous iteration looked): wait
-            // HERE, where everything this wave has produced is published -- a wave never spins on a RAW flag while it
-            // holds unpublished work, so the claim order cannot tie a knot
+            // rows not prefetched (first task, or their producers were not done when the previous iteration looked): publish
+            // everything this wave owes FIRST -- a wave never spins while it holds unpublished work -- then wait, then load
+            PT_ADD(6, 1);
             PT_BEGIN();
-            if (curd.raw_need > 0) dead = !wait_raw(curd);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            settle(j);
+            if (dma_pending >= 0) flush_owed();
+            wait_deps(curd, kRawMask, 4);
             PT_END(2);
-            PT_ADD(7, 1);
             if (dead) break;
             load_x(j, u, rxb, rxc);
         }
-        PT_TOP(3);      // publish, claim, deferred loads
-        const bool raw_ok2 = __builtin_amdgcn_readfirstlane(f_ra) >= nxt.raw_need && __builtin_amdgcn_readfirstlane(f_rb) >= nxt.raw_need &&
-                             __builtin_amdgcn_readfirstlane(f_rc) >= nxt.raw_need;
-        const bool war_ok2 = __builtin_amdgcn_readfirstlane(f_wa) >= nxt.war_need && __builtin_amdgcn_readfirstlane(f_wb) >= nxt.war_need;
-        const bool ld_ok2 = j2 < 2 || __builtin_amdgcn_readfirstlane(f_ld) >= j2;
 
-        PT_TOP(4);      // flag evaluation
-        PT_PHASE(0);      // TOP: loads issued, waited, published
-        const float* bdp = packed_n + (size_t)j * p.packed_stride + kBD + h * 32;
-        float bdr[32];           // dense bias of this lane's 32 output channels (global memory: the LDS is full of weights)
+        const float* bias = lds + kBiasF + (j & 1) * 64 + h * 32;
         float o[32];
         f32x16 acc2[2];
         // the next task's rows: requested between GEMM1 and GEMM2, in flight under GEMM2 + gating + stores
+        bool raw_ok2 = false, war_ok2 = false;
         auto prefetch_next = [&]() {
             if (u2 >= 0 && raw_ok2) {
                 load_x(j2, u2, rxb, rxc);
@@ -414,40 +437,67 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             }
             __builtin_amdgcn_sched_barrier(0);
         };
+        // drain + publish + leave, behind the first operand work of the unit (the P row and the previous unit's stores land
+        // meanwhile); then the verdict on the next task's dependencies
+        auto settle_top = [&]() {
+            if (!need_load) {
+                PT_BEGIN();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PT_END(1);
+                PT_BEGIN();
+                settle(j);
+                PT_END(4);
+            }
+            if (polledL) poll_finish(0, pvL, nxt.needL);
+            if (polledR) poll_finish(1, pvR, nxt.needR);
+            if (u2 >= 0) {
+                if (polledL || polledR) bad2 = eval(nxt);
+                claim_v = claim();
+            }
+            raw_ok2 = (bad2 & kRawMask) == 0;
+            war_ok2 = (bad2 & kWarMask) == 0;
+            PT_ADD(5, 1);
+        };
+        // the last fragment of the dense matrix (not in LDS): global memory, 16 bytes per lane
+        const float* lastfrag = packed_n + (size_t)j * p.packed_stride + kSlot + lane * 4;
+
         if constexpr (F32) {
             // ---- exact-fp32 arithmetic: v_mfma_f32_32x32x2_f32, the operands are the rows as loaded (pwv_layer.hip) ----
-            const float* Af = lds + (j & 1) * kSlot;                 // [kA1 | kA2] of this layer's packed block
+            settle_top();
+            const float* Af = lds + (j & 1) * kSlot;                 // [kA1 | kA2 minus its last fragment]
             f32x4 a[4];
+            f32x4 lf = {0.f, 0.f, 0.f, 0.f};
             auto bx = [&](int ks) -> float { return ks < 32 ? rxb[ks] : rxc[ks - 32]; };
-            PT_PHASE(1);
             a[0] = frag(Af, 0, 0, 16, 0, lane);
             a[1] = frag(Af, 0, 2, 16, 0, lane);
-            gemm_groups<16, 2, 0, 2>(Af, 0, lane, acc, a, bx, [](int) {}, [&](f32x4(&n)[4]) {
-                n[0] = frag(Af, 0, 1, 16, 0, lane);
-                n[1] = frag(Af, 0, 3, 16, 0, lane);
+            gemm_groups<16, 2, 0, 2>(Af, 0, lane, acc, a, bx, [](int) {}, [&](f32x4(&nf)[4]) {
+                nf[0] = frag(Af, 0, 1, 16, 0, lane);
+                nf[1] = frag(Af, 0, 3, 16, 0, lane);
             });
-            PT_PHASE(2);
             gemm_groups<16, 2, 1, 2>(
                 Af, 0, lane, acc, a, bx,
                 [&](int g) {
                     o[g] = gate_act(acc[0][g], acc[2][g]);
                     asm volatile("" : "+v"(o[g]));   // keep the gating inside this MFMA group (no sinking)
-                    if (g == 10) load_contig<8>(bdp, bdr);
+                    if (g == 10) lf = *reinterpret_cast<const f32x4*>(lastfrag);
                 },
-                [&](f32x4(&n)[4]) {
-                    n[0] = frag(Af, kA1Size, 0, 8, 0, lane);
-                    n[1] = frag(Af, kA1Size, 1, 8, 0, lane);
+                [&](f32x4(&nf)[4]) {
+                    nf[0] = frag(Af, kA1Size, 0, 8, 0, lane);
+                    nf[1] = frag(Af, kA1Size, 1, 8, 0, lane);
                 });
-            PT_PHASE(3);
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[it][r] = rxc[it * 16 + r] + bdr[it * 16 + r];
-            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bd = *reinterpret_cast<const f32x4*>(bias + it * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = rxc[it * 16 + q * 4 + e] + bd[e];
+                }
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(lf));
             prefetch_next();
-            PT_PHASE(4);
-            gemm_groups<8, 2, 0, 1>(
-                Af, kA1Size, lane, acc2, a, [&](int ks) -> float { return o[ks]; },
+            gemm_groups_dense(
+                [&](int it, int g) -> f32x4 { return (it == 1 && g == 7) ? lf : frag(Af, kA1Size, it, 8, g, lane); }, acc2, a,
+                [&](int ks) -> float { return o[ks]; },
                 [&](int g) {
                     if (g < 4) {
 #pragma unroll
@@ -456,8 +506,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                             asm volatile("" : "+v"(o[16 + 4 * g + e]));
                         }
                     }
-                },
-                [](f32x4(&)[4]) {});
+                });
         } else {
             const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
             const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
@@ -470,12 +519,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             split8<8>(rxb, bh[1], bl[1]);
             split8<16>(rxb, bh[2], bl[2]);
             split8<24>(rxb, bh[3], bl[3]);
+            settle_top();
             auto bxh = [&](int s) -> f16x8 { return bh[s]; };
             auto bxl = [&](int s) -> f16x8 { return bl[s]; };
             f16x8 oh[4], ol[4];
             f16x8 ah[4], al[4];
+            f16x8 lf = {0, 0, 0, 0, 0, 0, 0, 0};
 
-            PT_PHASE(1);      // x[t-d] split
             // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]); x[t] is split under its first four MFMA groups ------------
             first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
             gemm16<8, 2, 0, 2, 4>(
@@ -487,7 +537,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
                 },
                 [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
-            PT_PHASE(2);      // GEMM1 pair 0
             // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -----------------------------------
             gemm16<8, 2, 1, 2, 4>(
                 A1, lane, acc, ah, al, bxh, bxl,
@@ -497,28 +546,24 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
                     if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
                     if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
-#ifdef PWV_ABL_NOBD
-                    if (s == 5) { for (int k = 0; k < 32; ++k) bdr[k] = 0.f; }
-#else
-                    if (s == 5) load_contig<8>(bdp, bdr);
-#endif      // lands under the last two k-steps (x[t-d]'s operands are dead by now)
+                    if (s == 5) lf = *reinterpret_cast<const f16x8*>(lastfrag);      // lands under the last two k-steps
                 },
                 [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl); });
 
-            PT_PHASE(3);      // GEMM1 pair 1
             // ---- GEMM2: dense 64 -> 64, accumulator starts at x[t] + dense_bias ---------------------------------------------
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    const f32x4 bd = *reinterpret_cast<const f32x4*>(bias + it * 16 + q * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bdr[it * 16 + q * 4 + e];
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bd[e];
                 }
-            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(lf));
             prefetch_next();      // (xc is dead from here on)
-            PT_PHASE(4);      // acc2 init + prefetch issue
-            gemm16<4, 2, 0, 1, 2>(
-                A2, lane, acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
+            gemm16_dense(
+                [&](int comp, int it, int s) -> f16x8 { return (comp == 1 && it == 1 && s == 3) ? lf : frag16<4, 2>(A2, comp, it, s, lane); },
+                acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
                 [&](int s) {
                     if (s < 2) {   // k-steps 0,1 use o tile 0; gate + split tile 1 under them
 #pragma unroll
@@ -527,78 +572,69 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         else split8<24>(o, oh[3], ol[3]);
                         asm volatile("" : "+v"(oh[2 + (s & 1)]), "+v"(ol[2 + (s & 1)]));
                     }
-                },
-                [](f16x8(&)[4], f16x8(&)[4]) {});
-
+                });
         }
-        PT_PHASE(5);      // GEMM2
         // ---- stores (after the readers of the ring slot they overwrite are known to be done) -------------------------------
-        PT_BEGIN();
-        if (!war_ok) flush_owed();
-        if (!war_ok) dead = dead || !(spin_ge(flags + cur_wa, cur_wneed, p.status, 5, lane) && spin_ge(flags + cur_wb, cur_wneed, p.status, 5, lane));
-        PT_END(3);
+        if (!war_ok) {
+            PT_BEGIN();
+            flush_owed();
+            wait_deps(curd, kWarMask, 5);
+            PT_END(3);
+            if (dead) break;
+        }
         {
-            int shift;
-            const __amdgpu_buffer_rsrc_t ro = out_rsrc(j, shift);
-            const int oo = toff(row, shift);
-#ifdef PWV_ABL_NOSTORE
-            if (valid && acc2[0][0] == 1.2345e-30f) {      // keeps GEMM2 alive, never true
-#else
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(ring_of(mod3(j + p.rot)));
+            const int oo = toff(row);
+            // units the right neighbour reads as x[t-d] in the next layer are stored write-through
+            const int dn = dil_of(j + 1 < L ? j + 1 : j);
+            const bool shared = u + ((dn + 31) >> 5) >= u_end;
             if (valid) {
-#endif
+                if (shared) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int it = g >> 2, q = g & 3;
-                    const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-#ifdef PWV_ABL_NTSTORE
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, 2);
-#else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, PWV_PERSIST_STORE_AUX);
-#endif
+                    for (int g = 0; g < 8; ++g) {
+                        const int it = g >> 2, q = g & 3;
+                        const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, kAuxWriteThrough);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int it = g >> 2, q = g & 3;
+                        const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, PWV_PERSIST_STORE_AUX);
+                    }
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        PT_PHASE(6);      // stores
         // ---- move on ------------------------------------------------------------------------------------------------------
-        PT_BEGIN();
-        for (int jj = j; jj < (u2 >= 0 ? j2 : L); ++jj) leave_layer(jj);
-        PT_END(4);
-        prev_u = u; prev_j = j;
-        PT_BEGIN();
-        if (u2 >= 0 && j2 != j && !ld_ok2) { flush_owed(); dead = dead || !spin_ge(&wgctl[j2 & 1], j2, p.status, 3, lane); }
-        PT_END(5);
-        i = i2; j = j2; base = base2; u = u2; war_ok = war_ok2;
-        cur_wa = nxt.wa; cur_wb = nxt.wb; cur_wneed = nxt.war_need;
+        prev_u = u;
+        prev_j = j;
+        j = j2; u = u2;
+        war_ok = war_ok2;
         need_load = !raw_ok2;
         curd = nxt;
-        PT_PHASE(7);      // leave_layer / bookkeeping
     }
-    // the last unit's stores, and a refill this wave still owes its workgroup
+    // the last unit's stores, a refill this wave still owes, and the layers it has not yet counted itself out of
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!dead) {
+        settle(L);
+        if (dma_pending >= 0) flush_owed();
+    }
 #ifdef PWV_PTRACE
     if (p.trace && lane == 0) {
-        pt_acc[9] = __builtin_amdgcn_s_memtime();
-        pt_acc[0] = pt_acc[9] - pt_start;
-        long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 32;
-        for (int k = 0; k < 8; ++k) tr[16 + k] = pt_ph[k];
-        for (int k = 0; k < 5; ++k) { tr[24 + k] = pt_top[k]; }
+        pt_acc[8] = __builtin_amdgcn_s_memtime();
+        pt_acc[0] = pt_acc[8] - pt_start;
+        long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
         for (int k = 0; k < 10; ++k) tr[k] = pt_acc[k];
-        tr[10] = net; tr[11] = xcc; tr[12] = w;
-        tr[13] = pt_entry_rt; tr[14] = pt_start_rt; tr[15] = __builtin_amdgcn_s_memrealtime();
-        tr[30] = dead ? 1 : 0; tr[31] = ((long long)j << 32) | (unsigned)u;
-
+        tr[10] = net; tr[11] = w; tr[12] = dead ? 1 : 0; tr[13] = __builtin_amdgcn_s_memrealtime(); tr[14] = pt_start_rt;
     }
 #endif
-    if (prev_u >= 0 && !dead) st_word(flags + prev_u, prev_j + 1, lane);
-    if (dma_pending >= 0) st_word(&wgctl[dma_pending & 1], dma_pending, lane);
-    census();
 }
 
 // every polled word starts at zero on EVERY call.  A kernel, not hipMemsetAsync: under stream capture the memset node of a
-// torch-captured graph did not reset the words on replay (the replays then found every flag already satisfied and every
-// task already claimed -- fast and wrong; tests/test_gpu_persist.py::test_whole_model_persistent_eager_and_graph_replay)
+// torch-captured graph did not reset the words on replay (tests/test_gpu_persist.py::test_whole_model_persistent_eager_and_graph_replay)
 __global__ void persist_zero_kernel(int4* p, size_t n16) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n16) p[i] = int4{0, 0, 0, 0};
@@ -621,35 +657,48 @@ int pwv_persist_status(int** status) {
     return PWV_OK;
 }
 
-static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int& units, int& upx, int& strip_units,
-                        int& wpx, int* hu) {
+struct PersistPlan { int units, nwg, per_wg, last_wg, reach_wgs, xcd_map; };
+
+static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int max_wgs, int min_units, PersistPlan& pl) {
     PWV_CHECK_ARG(G >= 1 && G <= PWV_MAX_NETS, "persistent stack: G=%d out of range", G);
     PWV_CHECK_ARG(n_layers >= 2 && n_layers <= kMaxPLayers && dil, "persistent stack: 2..%d layers per launch, got %d", kMaxPLayers, n_layers);
     PWV_CHECK_ARG(rows >= 1 && rows < (1ll << 31) - 256, "persistent stack: bad N*T");
-    PWV_CHECK_ARG(cus >= 8 && cus % 8 == 0 && (cus / 8) % G == 0, "persistent stack: %d CUs do not split into 8 XCDs x %d nets", cus, G);
-    units = (int)((rows + 31) / 32);
-    upx = (units + 7) / 8;
-    wpx = cus / 8 / G;
-    hu[n_layers - 1] = 0;
-    for (int j = n_layers - 1; j > 0; --j) {
+    PWV_CHECK_ARG(cus >= G, "persistent stack: %d CUs for %d nets", cus, G);
+    int dmax = 1;
+    for (int j = 0; j < n_layers; ++j) {
         PWV_CHECK_ARG(dil[j] >= 1, "persistent stack: bad dilation");
-        hu[j - 1] = hu[j] + (dil[j] + 31) / 32;
+        dmax = dil[j] > dmax ? dil[j] : dmax;
     }
-    PWV_CHECK_ARG(dil[0] >= 1, "persistent stack: bad dilation");
-    strip_units = upx + hu[0];
-    PWV_CHECK_ARG((long long)strip_units * 8192 < (1ll << 32) && (long long)units * 8192 < (1ll << 32),
-                  "persistent stack: buffers beyond the 4 GB reach of a buffer descriptor");
+    pl.units = (int)((rows + 31) / 32);
+    PWV_CHECK_ARG((long long)pl.units * 8192 < (1ll << 32), "persistent stack: buffers beyond the 4 GB reach of a buffer descriptor");
+    int wgs = cus / G;                                  // every workgroup must be resident: one per CU (its LDS is the whole CU's)
+    if (max_wgs > 0 && max_wgs / G < wgs) wgs = max_wgs / G;
+    PWV_CHECK_ARG(wgs >= 1, "persistent stack: no workgroups");
+    // short inputs: at least `min_units` units per workgroup and layer: fewer workgroups instead of ranges of one or two units
+    // (default 4 = one per SIMD; measured at 16000 rows x 2 nets: 0.64 ms per forward with 4, 0.76 ms with 8)
+    if (min_units <= 0) min_units = 4;
+    int want = (pl.units + min_units - 1) / min_units;
+    if (want < 1) want = 1;
+    pl.nwg = wgs < want ? wgs : want;
+    pl.per_wg = (pl.units + pl.nwg - 1) / pl.nwg;
+    PWV_CHECK_ARG(pl.per_wg <= kMaxUnitsWg, "persistent stack: %d units per workgroup (max %d)", pl.per_wg, kMaxUnitsWg);
+    pl.last_wg = (pl.units - 1) / pl.per_wg;
+    const int reach = (dmax + 31) / 32;      // units a task looks back (RAW) / is looked back at from (WAR)
+    pl.reach_wgs = (reach + pl.per_wg - 1) / pl.per_wg;
+    PWV_CHECK_ARG(pl.reach_wgs <= kMaxReachWgs, "persistent stack: dilation %d reaches over %d workgroups (max %d)", dmax, pl.reach_wgs, kMaxReachWgs);
+    const int grid = G * pl.nwg;
+    pl.xcd_map = (pl.nwg % 8 == 0 && grid % 8 == 0) ? 1 : 0;
     return PWV_OK;
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-size_t pwv_persist_workspace_bytes(int G, int N, int T, int n_layers, const int* dilations) {
-    int units, upx, strip_units, wpx, hu[kMaxPLayers];
+size_t pwv_persist_workspace_bytes(const pwv_persist_args* a) {
+    PersistPlan pl;
     const int cus = device_cus();
-    if (persist_plan(G, (long long)N * T, n_layers, dilations, cus, units, upx, strip_units, wpx, hu) != PWV_OK) return 0;
-    const size_t ctl = align256((size_t)(kCtlHead + cus * kCtlWg) * 4 + (size_t)G * 8 * strip_units * 4);
-    return ctl + (size_t)G * 8 * kRing * strip_units * 2048 * 4;
+    if (!a) { set_error(PWV_EINVAL, "pwv_persist_workspace_bytes: NULL argument"); return 0; }
+    if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl) != PWV_OK) return 0;
+    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);
 }
 
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream) {
@@ -657,35 +706,39 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     const int cus = device_cus();
     if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
     PersistParams p{};
-    int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, p.units, p.upx, p.strip_units, p.wpx, p.hu);
+    PersistPlan pl;
+    int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl);
     if (rc != PWV_OK) return rc;
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_stack_persist_f32: bad N/T");
     PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32, "pwv_wavenet_stack_persist_f32: precision must be PWV_PREC_F16X3 or PWV_PREC_F32");
     PWV_CHECK_ARG(a->proj_row_stride % 4 == 0 && a->cond_hop >= 0, "pwv_wavenet_stack_persist_f32: bad projection arguments");
-    PWV_CHECK_ARG(a->workspace_bytes >= pwv_persist_workspace_bytes(a->G, a->N, a->T, a->n_layers, a->dilations),
-                  "pwv_wavenet_stack_persist_f32: workspace too small");
+    PWV_CHECK_ARG(a->workspace_bytes >= pwv_persist_workspace_bytes(a), "pwv_wavenet_stack_persist_f32: workspace too small");
     PWV_CHECK_ARG(((uintptr_t)a->workspace & 255) == 0, "pwv_wavenet_stack_persist_f32: workspace must be 256-byte aligned");
-    const size_t ctl_ints = (size_t)(kCtlHead + cus * kCtlWg);
-    const size_t ctl_bytes = align256(ctl_ints * 4 + (size_t)a->G * 8 * p.strip_units * 4);
-    char* ws = (char*)a->workspace;
-    p.ctl = (int*)ws;
+    p.prog = (int*)a->workspace;
     for (int g = 0; g < a->G; ++g) {
-        PWV_CHECK_ARG(a->x_in[g] && a->x_out[g] && a->packed_layers[g] && a->proj[g], "pwv_wavenet_stack_persist_f32: NULL buffer for net %d", g);
-        PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_stack_persist_f32: x_in and x_out must differ");
-        p.x_in[g] = a->x_in[g];
-        p.x_out[g] = a->x_out[g];
+        PWV_CHECK_ARG(a->x_ring[g] && a->packed_layers[g] && a->proj[g], "pwv_wavenet_stack_persist_f32: NULL buffer for net %d", g);
+        p.ring[g] = a->x_ring[g];
         p.packed[g] = a->packed_layers[g];
         p.proj[g] = a->proj[g];
-        p.flags[g] = (int*)ws + ctl_ints + (size_t)g * 8 * p.strip_units;
-        p.strips[g] = (float*)(ws + ctl_bytes) + (size_t)g * 8 * kRing * p.strip_units * 2048;
     }
     PWV_CHECK_HIP(pwv_persist_status(&p.status) == PWV_OK ? hipSuccess : hipErrorUnknown);
+    PWV_CHECK_ARG(a->ring_stride >= (size_t)pl.units * 2048 && a->ring_stride % 4 == 0,
+                  "pwv_wavenet_stack_persist_f32: ring_stride smaller than one tile32 buffer (%lld floats)", (long long)pl.units * 2048);
+    p.ring_stride = (long long)a->ring_stride;
     p.packed_stride = (long long)a->packed_layer_stride;
     p.proj_row_stride = a->proj_row_stride;
     p.G = a->G;
     p.N = a->N;
     p.T = a->T;
     p.n_layers = a->n_layers;
+    p.units = pl.units;
+    p.per_wg = pl.per_wg;
+    p.nwg = pl.nwg;
+    p.last_wg = pl.last_wg;
+    p.reach_wgs = pl.reach_wgs;
+    p.xcd_map = pl.xcd_map;
+    PWV_CHECK_ARG(a->ring_rotation >= 0 && a->ring_rotation < 3, "pwv_wavenet_stack_persist_f32: ring_rotation must be 0, 1 or 2");
+    p.rot = a->ring_rotation;
     p.cond_hop = a->cond_hop;
     p.cond_offset = a->cond_offset;
     p.cond_frames = a->cond_frames;
@@ -697,12 +750,12 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }
 #endif
     hipStream_t s = (hipStream_t)stream;
-    const size_t n16 = ctl_bytes / 16;
-    hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)ws, n16);
+    const size_t n16 = align256((size_t)a->G * pl.nwg * kProgStride * 4) / 16;
+    hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
     if (a->precision == PWV_PREC_F32)
-        hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(cus), dim3(512), 0, s, p);
+        hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
     else
-        hipLaunchKernelGGL(stack_persist_kernel<false>, dim3(cus), dim3(512), 0, s, p);
+        hipLaunchKernelGGL(stack_persist_kernel<false>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "persistent stack kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;

@@ -52,13 +52,19 @@ HOIST_P = os.environ.get('PWV_HOIST_P', '1') != '0'
 FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
 # PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
 FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
-# PWV_PERSIST=1: run the residual layers 1 .. L-2 of a stack as ONE persistent dataflow launch (csrc/pwv_stack_persist.hip,
-# bit-identical results) instead of one launch per layer.  OFF by default: measured under HIP-graph replay on MI355X it is
-# at parity with the two-stream per-layer launches at every size tried (C3 3.12 vs 3.07 ms per step, C4 9.81 vs 9.40 ms,
-# 1 s inputs 1.17 vs 0.94 ms) -- the per-unit issue time of the MFMA + VALU stream bounds both.
-PERSIST = os.environ.get('PWV_PERSIST', '0') != '0'
-# units per XCD (and net) the persistent launch wants per wave sharing them; tests set 0 to force it onto small inputs
-PERSIST_UNITS_PER_WAVE = float(os.environ.get('PWV_PERSIST_UNITS_PER_WAVE', '2'))
+# The residual layers 1 .. L-2 of a stack as ONE persistent launch (csrc/pwv_stack_persist.hip, bit-identical results)
+# instead of one launch per layer.  PWV_PERSIST = 0 | 1 | auto (default).  Measured on MI355X: at the
+# headline size (160000 rows) both forms sit at the package power cap and deliver the same samples per joule (+-1.5 %
+# between boxes), while on short inputs -- where the per-layer launches are bound by their prologues, tails and gaps, not by
+# power -- the persistent launch wins (default model, 16000 samples, graph replay: 0.80 -> 0.64 ms; 64000: -2.7 %).
+# 'auto' therefore takes it up to PERSIST_AUTO_MAX_ROWS rows per launch and the two-stream per-layer launches above.
+_pm = os.environ.get('PWV_PERSIST', 'auto')
+PERSIST = {'0': False, '1': True}.get(_pm, 'auto')
+PERSIST_AUTO_MAX_ROWS = int(os.environ.get('PWV_PERSIST_AUTO_MAX_ROWS', '72000'))
+# short inputs: fewer workgroups rather than ranges below this many units (0 = the library's default, 4)
+PERSIST_MIN_UNITS = int(os.environ.get('PWV_PERSIST_MIN_UNITS', '0'))
+# longest run of layers in one persistent launch (a stack's residual layers are cut into equal runs that hand the ring on)
+PERSIST_MAX_LAYERS = int(os.environ.get('PWV_PERSIST_MAX_LAYERS', '32'))
 _persist_status_addr = None
 _side_streams = {}
 
@@ -82,18 +88,39 @@ def raise_if_persist_failed() -> None:
     if code != 0:
         ctypes.c_int.from_address(_persist_status_addr).value = 0
         PERSIST = False
-        raise _lib.PwvError('the persistent stack kernel gave up (code %d); its outputs are invalid -- the per-layer path is '
-                            'used from now on, rerun the forward' % code)
+        raise _lib.PwvPersistError('the persistent stack kernel gave up (code %d); its outputs are invalid -- the per-layer path '
+                                   'is used from now on, rerun the forward' % code)
 
 
-def _persist_fits(G: int, rows: int, L: int) -> bool:
-    cus = _lib.lib().pwv_device_cus()
-    if L < 4 or cus < 8 or cus % 8 or (cus // 8) % G:
+def _persist_runs(L: int) -> List[Tuple[int, int]]:
+    """(first layer, count) of the persistent launches that cover the residual layers 1 .. L-2."""
+    Lp = L - 2
+    nchunks = -(-Lp // max(2, PERSIST_MAX_LAYERS))
+    runs, j0 = [], 1
+    for c in range(nchunks):
+        cnt = Lp // nchunks + (1 if c < Lp % nchunks else 0)
+        runs.append((j0, cnt))
+        j0 += cnt
+    if len(runs) > 1 and runs[-1][1] < 2:       # (a run has at least two layers)
+        runs[-2:] = [(runs[-2][0], runs[-2][1] + runs[-1][1])]
+    return runs
+
+
+def _use_persist(G: int, n: int, t: int, dilations) -> bool:
+    L = len(dilations)
+    if PERSIST is False or L < 4:
         return False
-    units = (rows + 31) // 32
-    upx = (units + 7) // 8
-    waves = 8 * (cus // 8 // G)
-    return units >= 64 and min(upx, units - 7 * upx) >= max(1.0, PERSIST_UNITS_PER_WAVE * waves)
+    if PERSIST == 'auto' and n * t > PERSIST_AUTO_MAX_ROWS:
+        return False
+    lib = _lib.lib()
+    for j0, cnt in _persist_runs(L):           # 0 bytes = the library cannot run this shape persistently: per-layer launches
+        pa = _lib.PersistArgs()
+        pa.G, pa.n_layers, pa.N, pa.T = G, cnt, n, t
+        pa.dilations = (ctypes.c_int * cnt)(*[int(d) for d in dilations[j0:j0 + cnt]])
+        pa.min_units_per_workgroup = PERSIST_MIN_UNITS
+        if lib.pwv_persist_workspace_bytes(ctypes.byref(pa)) == 0:
+            return False
+    return True
 
 
 def _net_streams(device):
@@ -401,7 +428,8 @@ def _same_structure(a, b) -> bool:
 
 def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec):
     """Layer 0 (one launch), layers 1 .. L-2 (ONE persistent launch), layer L-1 with the head behind it (one launch); all
-    nets of the flow in every launch, all on the current stream."""
+    nets of the flow in every launch, all on the current stream.  `bufs[g]` holds THREE tile32 buffers: the persistent
+    launch rotates through them (include/pwv_hip.h, pwv_persist_args.x_ring)."""
     G, L = len(nets), plans[0].n_layers
     net0 = nets[0]
     hop, offset, frames = cond_geom
@@ -421,7 +449,7 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         la.precision = prec
         return la
 
-    la = layer_args(0, 0, 1)
+    la = layer_args(0, 0, 2)                # (src is the causal layer's buffer unless layer 0 rebuilds it from x_first)
     la.out_mode = _lib.OUT_RESIDUAL
     if x_first is not None:
         la.x_first, la.x_limit, la.range_flag = _ptr(x_first), x_limit, range_flag_ptr()
@@ -429,34 +457,43 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
             la.causal_filter[g] = plans[g].causal_filter.data_ptr()
     check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
 
-    pa = _lib.PersistArgs()
-    pa.G, pa.n_layers = G, L - 2
-    dil = (ctypes.c_int * (L - 2))(*[int(d) for d in net0.dilations[1:L - 1]])
-    pa.dilations = dil
-    for g in range(G):
-        pa.x_in[g], pa.x_out[g] = bufs[g][1].data_ptr(), bufs[g][0].data_ptr()
-        pa.packed_layers[g] = plans[g].packed_layers.data_ptr() + 4 * stride
-        pa.proj[g] = projs[g].data_ptr() + 4 * 128
-    pa.packed_layer_stride = stride
-    pa.proj_row_stride = row_stride
-    pa.N, pa.T = n, t
-    pa.precision = prec
-    pa.cond_hop, pa.cond_offset, pa.cond_frames = hop, offset, frames
-    nbytes = lib.pwv_persist_workspace_bytes(G, n, t, L - 2, dil)
-    if nbytes == 0:
-        raise _lib.PwvError('pwv_persist_workspace_bytes: %s' % lib.pwv_last_error().decode())
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=bufs[0][0].device)
-    pa.workspace, pa.workspace_bytes = ws.data_ptr(), nbytes
-    ev = None
-    if EVENT_LOG is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
-    check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
-    if ev is not None:
-        ev[1].record()
-        EVENT_LOG.append(('persist', ev[0], ev[1], G, L - 2))
+    # the residual layers 1 .. L-2 as persistent launches of at most PERSIST_MAX_LAYERS layers each, handing the ring on
+    rot, out_slot = 0, 2
+    for j0, cnt in _persist_runs(L):
+        pa = _lib.PersistArgs()
+        pa.G, pa.n_layers = G, cnt
+        dil = (ctypes.c_int * cnt)(*[int(d) for d in net0.dilations[j0:j0 + cnt]])
+        pa.dilations = dil
+        for g in range(G):
+            pa.x_ring[g] = bufs[g][0].data_ptr()
+            pa.packed_layers[g] = plans[g].packed_layers.data_ptr() + 4 * stride * j0
+            pa.proj[g] = projs[g].data_ptr() + 4 * 128 * j0
+        pa.ring_stride = bufs[0][0].numel()
+        pa.ring_rotation = rot
+        pa.min_units_per_workgroup = PERSIST_MIN_UNITS
+        pa.packed_layer_stride = stride
+        pa.proj_row_stride = row_stride
+        pa.N, pa.T = n, t
+        pa.precision = prec
+        pa.cond_hop, pa.cond_offset, pa.cond_frames = hop, offset, frames
+        nbytes = lib.pwv_persist_workspace_bytes(ctypes.byref(pa))
+        if nbytes == 0:
+            raise _lib.PwvError('pwv_persist_workspace_bytes: %s' % lib.pwv_last_error().decode())
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=bufs[0][0].device)
+        pa.workspace, pa.workspace_bytes = ws.data_ptr(), nbytes
+        ev = None
+        if EVENT_LOG is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
+        if ev is not None:
+            ev[1].record()
+            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt))
+        out_slot = (cnt - 1 + rot) % 3      # where this run left its last layer
+        rot = (out_slot + 1) % 3            # the next run's input buffer is (2 + rot') % 3 == out_slot
+    spare = (out_slot + 1) % 3
 
-    la = layer_args(L - 1, 0, 1)
+    la = layer_args(L - 1, out_slot, spare)
     la.out_mode = _lib.OUT_GATED
     fuse_head = prec == _lib.PREC_F16X3 or (prec == _lib.PREC_F32 and FUSE_HEAD)
     if fuse_head:                        # the head runs inside the last layer's launch
@@ -469,7 +506,7 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         ha = _lib.HeadArgs()
         ha.G = G
         for g in range(G):
-            ha.in_[g], ha.packed[g], ha.out[g] = bufs[g][1].data_ptr(), plans[g].packed_head.data_ptr(), outs[g].data_ptr()
+            ha.in_[g], ha.packed[g], ha.out[g] = bufs[g][spare].data_ptr(), plans[g].packed_head.data_ptr(), outs[g].data_ptr()
         ha.N, ha.T, ha.Q = n, t, net0.out_channels
         ha.in_mode, ha.precision = _lib.HEAD_IN_GATED, prec
         check(lib.pwv_wavenet_head_f32(ctypes.byref(ha), s), 'pwv_wavenet_head_f32')
@@ -606,8 +643,8 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
     main = torch.cuda.current_stream()
     use_skip = bool(net0.use_skip_connection)
-    persist = (PERSIST and (prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
-               and max_workgroups == 0 and _persist_fits(G, rows, L))
+    persist = ((prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
+               and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations))
     two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
     row_stride = 128 * L
@@ -633,7 +670,10 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
 
     # ---- causal layer (modules.py:174-183) ----------------------------------------------------
     R = net0.residual_channels
-    bufs = [[tile_buf(R, torch.float16 if half else torch.float32) for _ in range(2)] for _ in nets]
+    if persist:      # the persistent launch rotates through three buffers of one allocation (pwv_persist_args.x_ring)
+        bufs = [list(torch.empty((3, lib.pwv_tile32_floats(rows, R)), dtype=torch.float32, device=dev).unbind(0)) for _ in nets]
+    else:
+        bufs = [[tile_buf(R, torch.float16 if half else torch.float32) for _ in range(2)] for _ in nets]
     # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
     # (pwv_layer_args.x_first), so the [rows, 64] front buffer is neither written nor read
     first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32) and qin == 1 and net0.filter_width == 2 and R == 64

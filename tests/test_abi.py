@@ -78,7 +78,7 @@ def test_header_is_plain_c():
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = ('#include <stdio.h>\n#include "pwv_hip.h"\nint main(void){ printf("%zu %zu %zu\\n", sizeof(pwv_layer_args), '
-           'sizeof(pwv_head_args), sizeof(pwv_stack_args)); return 0; }\n')
+           'sizeof(pwv_head_args), sizeof(pwv_stack_args)); printf("%zu\\n", sizeof(pwv_persist_args)); return 0; }\n')
     with tempfile.TemporaryDirectory() as d:
         c, exe = os.path.join(d, 't.c'), os.path.join(d, 't')
         with open(c, 'w') as f:
@@ -86,7 +86,7 @@ def test_header_is_plain_c():
         subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I' + os.path.join(root, 'include'), c, '-o', exe])
         sizes = [int(x) for x in re.findall(r'\d+', subprocess.check_output([exe]).decode())]
     from pwv_amd import _lib
-    assert sizes == [ctypes.sizeof(_lib.LayerArgs), ctypes.sizeof(_lib.HeadArgs), ctypes.sizeof(_lib.StackArgs)]
+    assert sizes == [ctypes.sizeof(_lib.LayerArgs), ctypes.sizeof(_lib.HeadArgs), ctypes.sizeof(_lib.StackArgs), ctypes.sizeof(_lib.PersistArgs)]
 
 
 def test_plain_c_client_builds(tmp_path):

@@ -1,9 +1,10 @@
-"""-m gpu: the persistent dataflow kernel for the residual layers of a stack (csrc/pwv_stack_persist.hip) against the
-per-layer launches -- BIT-identical by construction (same per-unit arithmetic; only the schedule, the buffers and the
-synchronisation differ), on shapes that exercise every protocol path: the production regime (many units per wave), XCDs
-with fewer units than waves (claims span several layers: weight refills and flag publications overlap), one net and two,
-several utterances per batch (x[t-d] = 0 at utterance starts inside an XCD's range), 30-layer stacks (halo of 91 units),
-and the whole model under HIP-graph replay.  Reference loop: modules.py:138-143."""
+"""-m gpu: the persistent kernel for the residual layers of a stack (csrc/pwv_stack_persist.hip) against the per-layer
+launches -- BIT-identical by construction (same per-unit arithmetic; only the schedule, the buffers and the synchronisation
+differ), on shapes that exercise every protocol path: the production regime (40 units per workgroup: the x[t-d] look-back
+of d = 512 reaches the left neighbour's top 16 units), ranges of one to four units (the look-back crosses up to 17
+workgroups, waves run several layers apart: weight refills, progress words and the 3-buffer ring all matter), one net and
+two, several utterances per batch (x[t-d] = 0 at utterance starts inside a range), 30-layer stacks, stacks cut into several
+runs that hand the ring on, and the whole model under HIP-graph replay.  Reference loop: modules.py:138-143."""
 import ctypes
 
 import numpy as np
@@ -32,15 +33,21 @@ def _nets(gpu, L, G, seed=3):
 @pytest.fixture()
 def persist_knobs():
     from pwv_amd import engine
-    saved = (engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE)
+    saved = (engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS)
     yield engine
-    engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE = saved
+    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS = saved
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
-@pytest.mark.parametrize('n,t,L,G', [(1, 160000, 10, 2), (1, 16000, 10, 2), (1, 8000, 30, 2), (1, 64000, 30, 1), (1, 2400, 6, 2),
-                                     (3, 8000, 10, 2), (5, 1040, 7, 1), (1, 65536, 4, 2)])
-def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G, precision):
+@pytest.mark.parametrize('n,t,L,G,min_units,max_layers', [
+    (1, 160000, 10, 2, 0, 32), (1, 16000, 10, 2, 0, 32), (1, 8000, 30, 2, 0, 32), (1, 64000, 30, 1, 0, 32), (1, 2400, 6, 2, 0, 32),
+    (3, 8000, 10, 2, 0, 32), (5, 1040, 7, 1, 0, 32), (1, 65536, 4, 2, 0, 32),
+    (1, 16000, 12, 2, 1, 32),       # one unit per workgroup: every look-back is a neighbour's, d = 512 reaches 16 workgroups back
+    (2, 24000, 30, 2, 2, 32),       # two units per workgroup over 30 layers, two utterances
+    (1, 160000, 30, 2, 0, 10),      # 28 residual layers as three runs (10 + 9 + 9) that hand the ring on
+    (1, 48000, 13, 1, 0, 4),        # 11 residual layers as runs of 4 + 4 + 3: every ring rotation
+    (1, 96, 5, 2, 0, 32)])          # three units in all
+def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G, min_units, max_layers, precision):
     import torch
     engine = persist_knobs
     store, nets = _nets(gpu, L, G)
@@ -55,7 +62,7 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
     store.version += 1
     engine.PERSIST = False
     ref = [o.clone() for o in engine.run_nets(nets, x, cond, precision=precision)]
-    engine.PERSIST, engine.PERSIST_UNITS_PER_WAVE = True, 0.0      # force the persistent path whatever the size
+    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS = True, min_units, max_layers      # forced, whatever the size
     log = engine.EVENT_LOG = []
     try:
         for _ in range(3):
@@ -66,7 +73,8 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
                 assert torch.equal(a, b)
     finally:
         engine.EVENT_LOG = None
-    assert [e[0] for e in log] == ['persist'] * 3 and log[0][4] == L - 2       # it really was the persistent launch
+    runs = engine._persist_runs(L)
+    assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 2)      # it really was persistent
 
 
 def test_whole_model_persistent_eager_and_graph_replay(gpu, persist_knobs):
@@ -107,11 +115,26 @@ def test_persistent_give_up_is_loud_and_falls_back(gpu, persist_knobs):
     """The kernel reports a give-up (unexpected placement, a poll that ran into its bound) through a sticky word in pinned
     host memory; the host then raises and uses the per-layer path from then on.  (The word is poked from the host here:
     a real give-up needs a broken chip.)"""
-    from pwv_amd._lib import PwvError
+    from pwv_amd._lib import PwvPersistError
     engine = persist_knobs
     engine.PERSIST = True
     assert engine.persist_status() == 0
     ctypes.c_int.from_address(engine._persist_status_addr).value = 4
-    with pytest.raises(PwvError, match='gave up'):
+    with pytest.raises(PwvPersistError, match='gave up'):
         engine.raise_if_persist_failed()
     assert engine.PERSIST is False and engine.persist_status() == 0
+
+
+def test_auto_policy_takes_the_persistent_launch_for_short_inputs_only(gpu, persist_knobs):
+    """PWV_PERSIST=auto (the default): the persistent launch up to PERSIST_AUTO_MAX_ROWS rows per launch (where it wins),
+    the two-stream per-layer launches above (parity at the power cap); shapes the library refuses (here: a
+    look-back over more neighbours than one wave instruction polls) silently take the per-layer path."""
+    engine = persist_knobs
+    engine.PERSIST = 'auto'
+    assert engine._use_persist(2, 1, 16000, D10) and engine._use_persist(1, 3, 16000, D10 * 3)
+    assert not engine._use_persist(2, 1, 160000, D10) and not engine._use_persist(2, 1, 16000, D10[:3])
+    engine.PERSIST, engine.PERSIST_MIN_UNITS = True, 1
+    assert engine._use_persist(2, 1, 160000, D10)
+    assert not engine._use_persist(2, 1, 3200, [1, 2, 4, 4096, 8, 16])       # 129 units back at one unit per workgroup
+    engine.PERSIST = False
+    assert not engine._use_persist(2, 1, 16000, D10)

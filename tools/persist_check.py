@@ -32,7 +32,6 @@ def main():
     x = torch.randn((1, rows, 1), generator=g).to(dev)
     frames = torch.rand((1, rows // hop + 1, 80), generator=g).to(dev)
     cond = engine.RepeatedCondition(frames, hop, hop // 2, rows)
-    engine.PERSIST_UNITS_PER_WAVE = float(os.environ.get("UPW", "2"))
     engine.run_nets(nets, x, cond, precision=prec)          # creates variables
     for name in list(store.vars):
         if store.vars[name].dim() == 1:
@@ -78,6 +77,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        if persist:
+            log = engine.EVENT_LOG = []
+            for _ in range(reps):
+                engine.run_nets(nets, x, cond, precision=prec)
+            torch.cuda.synchronize()
+            engine.EVENT_LOG = None
+            ts = [a.elapsed_time(b) * 1e3 for tag, a, b, _, _ in log if tag == 'persist']
+            print('persistent launch alone (zero kernel + %d layers): %s us = %.1f us per layer-pair' % (L - 2, ['%.0f' % v for v in ts], min(ts) / (L - 2)))
         print('%s: %.3f ms per stack call (%d nets x %d layers x %d rows) = %.1f us per layer-pair, status %d'
               % ('persistent' if persist else 'per-layer ', ms, G, L, rows, ms * 1e3 / L, engine.persist_status()), flush=True)
     return 0 if ok else 1

@@ -29,57 +29,39 @@ def main():
     x = torch.randn((1, rows, 1), generator=g).to(dev)
     frames = torch.rand((1, rows // hop + 1, 80), generator=g).to(dev)
     cond = engine.RepeatedCondition(frames, hop, hop // 2, rows)
-    trace = torch.zeros((2 * 256 * 8, 32), dtype=torch.int64, device=dev)
+    trace = torch.zeros((2 * 256 * 8, 16), dtype=torch.int64, device=dev)
     os.environ['PWV_PTRACE_PTR'] = str(trace.data_ptr())
     engine.PERSIST = True
-    engine.PERSIST_UNITS_PER_WAVE = float(os.environ.get('UPW', '2'))
     for _ in range(3):
         engine.run_nets(nets, x, cond)
     torch.cuda.synchronize()
     trace.zero_()
     engine.run_nets(nets, x, cond)
     torch.cuda.synchronize()
-    raw = trace.cpu().numpy()
-    diag = raw[2048:]
-    bad = diag[diag[:, 0] != 0]
-    if len(bad):
-        print('GIVE-UPS: %d waves; by code %s' % (len(bad), {int(c): int((bad[:, 0] == c).sum()) for c in np.unique(bad[:, 0])}))
-        for c in np.unique(bad[:, 0]):
-            b = bad[bad[:, 0] == c]
-            pairs = {}
-            for r in b:
-                pairs[(int(r[1]), int(r[2]))] = pairs.get((int(r[1]), int(r[2])), 0) + 1
-            print('  code %d: (need, value) -> count: %s' % (c, sorted(pairs.items())[:12]))
-        st = raw[:2048]
-        st = st[(st[:, 6] > 0) | (st[:, 30] != 0)]
-        print('  final (layer, unit) of dead waves: %s' % sorted(set((int(r[31] >> 32), int(r[31] & 0xffffffff)) for r in st if r[30]))[:40])
-    t = raw[:2048].astype(np.float64)
-    t = t[t[:, 6] > 0]
-    names = ['loop total', 'TOP wait vmcnt(0)', 'RAW spins', 'WAR spins', 'leave_layer', 'weight-ready spins']
-    print('%d waves, units per wave: mean %.1f (min %d, max %d); status %d' % (len(t), t[:, 6].mean(), t[:, 6].min(), t[:, 6].max(), engine.persist_status()))
+    t = trace.cpu().numpy().astype(np.float64)
+    t = t[t[:, 5] > 0]
+    # per wave: [0] loop cycles, [1] drain at the top, [2] RAW spins (incl. the publish in front), [3] WAR spins, [4] settle,
+    # [5] units, [6] units whose rows were not prefetched, [7]/[8] first task at / last task done at (s_memtime), [12] gave up
+    print('%d waves, units per wave: mean %.1f (min %d, max %d); status %d; waves that gave up: %d'
+          % (len(t), t[:, 5].mean(), t[:, 5].min(), t[:, 5].max(), engine.persist_status(), int(t[:, 12].sum())))
     tot = t[:, 0]
-    print('loop cycles per wave: mean %.0f, min %.0f, max %.0f; per unit %.0f' % (tot.mean(), tot.min(), tot.max(), (tot / t[:, 6]).mean()))
-    for k in range(1, 6):
-        print('  %-22s %6.1f %% of the loop (mean %.0f cycles per unit, max wave %.1f %%)'
-              % (names[k], 100 * t[:, k].sum() / tot.sum(), (t[:, k] / t[:, 6]).mean(), 100 * (t[:, k] / tot).max()))
-    ph = ['TOP (P + flag loads, wait, publish)', 'split x[t-d]', 'GEMM1 pair 0 (48 MFMA)', 'GEMM1 pair 1 (48 MFMA) + gate', 'acc2 init + prefetch issue',
-          'GEMM2 (24 MFMA) + gate', 'WAR check + stores', 'leave_layer / bookkeeping']
-    for k, name in enumerate(ph):
-        print('  phase %-38s %6.0f cycles per unit (%4.1f %%)' % (name, (t[:, 16 + k] / t[:, 6]).mean(), 100 * t[:, 16 + k].sum() / tot.sum()))
-    for k, name in enumerate(['unit_rows + P loads issued', 'claim read, locate, deps, flag loads issued', 'wait vmcnt(0)', 'publish, claim, deferred loads', 'flag evaluation']):
-        print('    TOP part %-46s %6.0f cycles per unit' % (name, (t[:, 24 + k] / t[:, 6]).mean()))
-    print('  units that had to spin on RAW: %.2f %%' % (100 * t[:, 7].sum() / t[:, 6].sum()))
-    # chip-wide 100 MHz clock: absolute picture in microseconds from the first wave's entry
-    t0 = t[:, 13].min()
-    ent, st, en = (t[:, 13] - t0) / 100.0, (t[:, 14] - t0) / 100.0, (t[:, 15] - t0) / 100.0
-    print('kernel entry: %.1f .. %.1f us; loop start: %.1f .. %.1f us; loop end: %.1f .. %.1f us' % (ent.min(), ent.max(), st.min(), st.max(), en.min(), en.max()))
-    clk = tot / ((t[:, 15] - t[:, 14]) / 100.0) / 1e3
+    print('loop cycles per wave: mean %.0f, min %.0f, max %.0f; per unit %.0f (steady: two waves share a SIMD)'
+          % (tot.mean(), tot.min(), tot.max(), (tot / t[:, 5]).mean()))
+    for k, name in ((1, 'drain vmcnt(0) at the top'), (2, 'not-prefetched path (publish + RAW spins)'), (3, 'WAR spins'), (4, 'settle (publish / leave / refill issue)')):
+        print('  %-44s %6.2f %% of the loop (mean %.0f cycles per unit, worst wave %.1f %%)'
+              % (name, 100 * t[:, k].sum() / tot.sum(), (t[:, k] / t[:, 5]).mean(), 100 * (t[:, k] / tot).max()))
+    print('  units whose rows were NOT prefetched: %.2f %%' % (100 * t[:, 6].sum() / t[:, 5].sum()))
+    t0 = t[:, 14].min()
+    st, en = (t[:, 14] - t0) / 100.0, (t[:, 13] - t0) / 100.0
+    print('loop start %.1f .. %.1f us, loop end %.1f .. %.1f us (chip-wide 100 MHz clock)' % (st.min(), st.max(), en.min(), en.max()))
+    clk = tot / ((t[:, 13] - t[:, 14]) / 100.0) / 1e3
     print('shader clock during the loop (s_memtime cycles / s_memrealtime): mean %.3f GHz (min %.3f, max %.3f)' % (clk.mean(), clk.min(), clk.max()))
-    for xcc in range(8):
-        m = t[:, 11] == xcc
-        if m.any():
-            print('  XCD %d: %d waves, loop start %.1f..%.1f us, end %.1f..%.1f us, %.0f cycles per unit'
-                  % (xcc, m.sum(), st[m].min(), st[m].max(), en[m].min(), en[m].max(), (tot[m] / t[m, 6]).mean()))
+    per_wg = {}
+    for r in t:
+        per_wg.setdefault((int(r[10]), int(r[11])), []).append(r[0])
+    wg_tot = np.array([max(v) for v in per_wg.values()])
+    print('workgroups: %d; slowest wave per workgroup: mean %.0f, min %.0f, max %.0f cycles (spread %.1f %%)'
+          % (len(wg_tot), wg_tot.mean(), wg_tot.min(), wg_tot.max(), 100 * (wg_tot.max() - wg_tot.min()) / wg_tot.mean()))
 
 
 if __name__ == '__main__':

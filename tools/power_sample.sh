@@ -1,6 +1,8 @@
 #!/bin/bash
+# (environment of the caller is inherited: e.g. PWV_PERSIST=1 tools/power_sample.sh; BENCH_ARGS adds bench flags)
+BENCH_ARGS=${BENCH_ARGS:-}
 # package power / clocks under the headline workload (profiles/rNN_power_clock.md): bench in the background, rocm-smi sampled
-python bench.py --steps 2500 --warmup 5 --no-cpu-baseline --no-f32-exact > /tmp/bench_bg.log 2>&1 &
+python bench.py --steps ${STEPS:-2500} --warmup 5 --no-cpu-baseline --no-f32-exact $BENCH_ARGS > /tmp/bench_bg.log 2>&1 &
 pid=$!
 sleep 16
 for i in 1 2 3 4 5; do
