@@ -86,10 +86,8 @@ struct PersistParams {
 #define PT_ADD(k, v) do {} while (0)
 #endif
 
-// dependencies of one task as (LDS byte address, required value) pairs, wave-uniform:
-// [0] own x[t] rows, [1] [2] x[t-d] rows, [3] this layer's weights resident (RAW side); [4] [5] readers of the slot it overwrites (WAR)
-// Kept as ONE VGPR (lane k holds pair k packed as need << 20 | address) plus what the neighbours' progress must reach.
-struct Deps { int v; int needL, needR; };
+// dependency bits of a task: [0] own x[t] rows, [1] [2] x[t-d] rows, [3] this layer's weights resident (RAW side);
+// [4] [5] readers of the ring slot it overwrites (WAR)
 constexpr unsigned kRawMask = 0xFu, kWarMask = 0x30u;
 
 // GEMM2 (dense, K = 64) with the fragment source as a functor: the persistent kernel takes the last fragment from a register
@@ -174,13 +172,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     const int n = u_end - u_begin;
     if (n <= 0) return;      // owns nothing; nobody waits for it (the neighbour sets stop at the last owning workgroup)
     const int L = p.n_layers;
-    const int wl = w - p.reach_wgs > 0 ? w - p.reach_wgs : 0;
-    const int nL = w - wl;
-    const int wr = w + p.reach_wgs < p.last_wg ? w + p.reach_wgs : p.last_wg;
-    const int nR = wr - w;
 
-    int* ctl = reinterpret_cast<int*>(lds + kCtlF);
-    volatile unsigned char* lb = reinterpret_cast<volatile unsigned char*>(lds);
+    typedef __attribute__((address_space(3))) int* lds_ints_t;
+    const lds_ints_t ctl = (lds_ints_t)(lds + kCtlF);
+    // (an LDS-address-space pointer: through a generic one the byte accesses become flat_load / flat_store and count on vmcnt)
+    typedef __attribute__((address_space(3))) volatile unsigned char* lds_bytes_t;
+    const lds_bytes_t lb = (lds_bytes_t)lds;
     int* prog_n = p.prog + (size_t)net * p.nwg * kProgStride;
     const float* const proj_n = p.proj[net];
     const float* const packed_n = p.packed[net];
@@ -193,8 +190,8 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     for (int k = tid; k < (kLdsFloats - kCtlF); k += 512) ctl[k] = 0;
     __syncthreads();
     if (tid == 0) {
-        lb[kSeenLB] = nL ? 0 : 255;
-        lb[kSeenRB] = nR ? 0 : 255;
+        lb[kSeenLB] = w > 0 ? 0 : 255;
+        lb[kSeenRB] = w < p.last_wg ? 0 : 255;
         lb[kWreadyB] = 0;
         lb[kWreadyB + 1] = 1;
         lb[kTrueB] = 255;
@@ -213,36 +210,38 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     __syncthreads();
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-    const unsigned full_bytes = (unsigned)p.units * 8192u;
-    auto make_rsrc = [&](const float* base) -> __amdgpu_buffer_rsrc_t {
-        const unsigned long long a = (unsigned long long)base;
+    // ONE buffer descriptor for the three ring buffers (they are one allocation); the buffer of a layer is selected by the
+    // scalar offset operand of the load / store.  sc1 loads: L2-served, never the CU's L1.
+    const __amdgpu_buffer_rsrc_t ring_rs = [&]() {
+        const unsigned long long a = (unsigned long long)p.ring[net];
+        const unsigned long long span = (unsigned long long)p.ring_stride * 8ull + (unsigned long long)p.units * 8192ull;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, __builtin_amdgcn_readfirstlane(full_bytes), 0x00020000);
-    };
-    float* const ring_n = p.ring[net];
-    auto ring_of = [&](int s) -> float* { return ring_n + (size_t)s * p.ring_stride; };
-    auto mod3 = [](int v) -> int { return v % 3; };
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, __builtin_amdgcn_readfirstlane((unsigned)span), 0x00020000);
+    }();
+    const int slot_bytes = (int)(p.ring_stride * 4);
+    auto in_soff = [&](int j) -> int { return ((j + 2 + p.rot) % 3) * slot_bytes; };
+    auto out_soff = [&](int j) -> int { return ((j + p.rot) % 3) * slot_bytes; };
     auto toff = [&](int row) -> int { return ((row >> 5) * 2048 + h * 128 + (row & 31) * 4) * 4; };
 
-    // x[t-d] / x[t] rows of one unit -> registers through sc1 loads (L2-served, never the CU's L1)
+    // x[t-d] / x[t] rows of one unit -> registers
     auto load_x = [&](int j, int unit, float (&xb)[32], float (&xc)[32]) {
         int row, rc, nn, t;
         bool valid;
         unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
-        const __amdgpu_buffer_rsrc_t r = make_rsrc(ring_of(mod3(j + 2 + p.rot)));
+        const int so = in_soff(j);
         const int d = dil_of(j);
         const bool has_prev = t >= d;
         const int oc = toff(rc), ob = toff(has_prev ? rc - d : rc);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, oc + g * 1024, 0, 16));
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, oc + g * 1024, so, 16));
 #pragma unroll
             for (int e = 0; e < 4; ++e) xc[4 * g + e] = v[e];
         }
         auto load_b = [&](bool keep) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ob + g * 1024, 0, 16));
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, ob + g * 1024, so, 16));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xb[4 * g + e] = keep ? v[e] : 0.f;
             }
@@ -251,99 +250,96 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         else load_b(has_prev);
     };
 
-    // ---- dependencies ------------------------------------------------------------------------------------------------
-    auto deps_of = [&](int j, int u) -> Deps {
-        Deps q;
-        const int d = dil_of(j);
-        const int ua = u - ((d + 31) >> 5), ub = (32 * u + 31 - d) >> 5;
-        q.needL = 0;
-        q.needR = 0;
-        q.v = kTrueB;                     // (need 0 at the always-255 byte: satisfied)
-        auto put = [&](int k, int addr, int need) { q.v = lane == k ? ((need << 20) | addr) : q.v; };
-        if (j >= 1) put(0, kDoneB + (u - u_begin), j);
-        auto left = [&](int v, int k) {
-            if (j < 1 || v < 0) return;
-            if (v >= u_begin) put(k, kDoneB + (v - u_begin), j);
-            else { put(k, kSeenLB, j); q.needL = j; }
-        };
-        left(ua, 1);
-        left(ub, 2);
-        if (j >= 2) put(3, kWreadyB + (j & 1), j);
-        const int d2 = dil_of(j >= 2 ? j - 2 : 0);
-        auto right = [&](int v, int k) {
-            if (j < 2 || v > p.units - 1) return;
-            if (v < u_end) put(k, kDoneB + (v - u_begin), j - 1);
-            else { put(k, kSeenRB, j - 1); q.needR = j - 1; }
-        };
-        right(u + (d2 >> 5), 4);
-        right(u + ((d2 + 31) >> 5), 5);
-        return q;
+    // ---- dependencies: lane k < 6 of a wave looks at ONE byte of LDS ------------------------------------------------------
+    //   k = 0: own x[t] rows, 1 / 2: the x[t-d] rows (units u - ceil(d/32), u - floor(d/32)), 3: this layer's weights resident,
+    //   4 / 5: the readers of the ring slot the task overwrites (layer j-2's tasks of the units u + floor(d'/32), u + ceil(d'/32)).
+    // Per layer: the unit offsets and the values the bytes must have reached (two VGPRs); per task: one address VGPR.
+    int vpack = 0;                     // need << 16 | (unit offset & 0xffff)
+    auto layer_vectors = [&](int j) {
+        const int d = dil_of(j), d2 = dil_of(j >= 2 ? j - 2 : 0);
+        const int off = lane == 1 ? -((d + 31) >> 5) : (lane == 2 ? -(d >> 5) : (lane == 4 ? (d2 >> 5) : (lane == 5 ? ((d2 + 31) >> 5) : 0)));
+        const int raw = j >= 1 ? j : 0, wts = j >= 2 ? j : 0, war = j >= 2 ? j - 1 : 0;
+        const int need = lane < 3 ? raw : (lane == 3 ? wts : (lane < 6 ? war : 0));
+        vpack = (need << 16) | (off & 0xffff);
     };
-    // bit k set: dependency k is NOT yet satisfied (one per-lane byte read of LDS)
-    auto eval = [&](const Deps& q) -> unsigned {
-        const int got = lb[q.v & 0xFFFFF];
-        return (unsigned)__ballot(got < (q.v >> 20));
+    auto dep_addr = [&](int j, int u) -> int {
+        const int v = u + (int)(short)vpack;
+        int a = kDoneB - u_begin + v;
+        a = v < u_begin ? kSeenLB : a;
+        a = v >= u_end ? kSeenRB : a;
+        a = (v < 0 || v >= p.units) ? kTrueB : a;
+        a = lane == 3 ? kWreadyB + (j & 1) : a;
+        return lane >= 6 ? kTrueB : a;
     };
+    // bit k set: dependency k is NOT yet satisfied
+    auto eval = [&](int addr) -> unsigned { return (unsigned)__ballot((int)lb[addr] < (vpack >> 16)); };
     // neighbours' progress words -> the cached "seen" byte of that side (only ever raised to a value that was observed)
-    auto poll_issue = [&](int side) -> int {
-        const int cnt = side ? nR : nL, w0 = side ? w + 1 : wl;
+    auto poll_side = [&](int side, int need) {
+        const int w0 = side ? w + 1 : (w - p.reach_wgs > 0 ? w - p.reach_wgs : 0);
+        const int cnt = side ? (w + p.reach_wgs < p.last_wg ? p.reach_wgs : p.last_wg - w) : w - w0;
         int v = 1 << 20;
         if (lane < cnt) v = __hip_atomic_load(prog_n + (size_t)(w0 + lane) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return v;
-    };
-    auto poll_finish = [&](int side, int v, int need) {
-        if (__ballot(v < need) == 0 && lane == 0) lb[side ? kSeenRB : kSeenLB] = (unsigned char)need;
+        if (__ballot(v < need) == 0) lb[side ? kSeenRB : kSeenLB] = (unsigned char)need;
     };
 
-    // Before a wave waits for anybody it publishes everything it owes: the unit it has just stored and a weight refill it
-    // has issued (both become true at a vmcnt(0)).
-    int prev_u = -1, prev_j = 0;
-    int dma_pending = -1;          // layer whose LDS-DMA this wave issued and has not yet announced
-    int left_upto = 0;             // layers [0, left_upto) this wave has counted itself out of
+    // what this wave owes the others: the unit it has just stored and a weight refill it has issued (true at a vmcnt(0))
+    int prev_addr = -1, prev_j = 0;      // LDS byte of the unit stored last, its layer
+    int dma_pending = -1;                // layer whose LDS-DMA this wave issued and has not yet announced
+    int left_upto = 0;                   // layers [0, left_upto) this wave has counted itself out of
     bool dead = false;
+    auto publish = [&]() {               // (all lanes store the same byte: no exec juggling)
+        if (prev_addr >= 0) { lb[prev_addr] = (unsigned char)(prev_j + 1); prev_addr = -1; }
+        if (dma_pending >= 0) { lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
+    };
     auto flush_owed = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (prev_u >= 0) { if (lane == 0) lb[kDoneB + (prev_u - u_begin)] = (unsigned char)(prev_j + 1); prev_u = -1; }
-        if (dma_pending >= 0) { if (lane == 0) lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
+        publish();
     };
-    // leaving layer jj (called after a drain: this wave's layer-jj stores are complete).  The LAST of the 8 waves publishes
-    // the workgroup's progress and refills the LDS slot with layer jj + 2.
-    auto leave_layer = [&](int jj) {
-        int old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[8 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old == 7) {
-            if (lane == 0) __hip_atomic_store(prog_n + (size_t)w * kProgStride, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (jj + 2 < L) {
-                if (dma_pending >= 0) flush_owed();       // (last twice in a row: announce the earlier refill first)
-                fill_slot(jj & 1, jj + 2, 0, 1);
-                dma_pending = jj + 2;
+    // leaving layer jj (after a drain: this wave's layer-jj stores are complete).  The LAST of the 8 waves publishes the
+    // workgroup's progress and refills the LDS slot with layer jj + 2.
+    auto leave_layers = [&](int upto) {
+        for (; left_upto < upto; ++left_upto) {
+            const int jj = left_upto;
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(&ctl[8 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 7) {
+                if (lane == 0) __hip_atomic_store(prog_n + (size_t)w * kProgStride, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (jj + 2 < L) {
+                    if (dma_pending >= 0) flush_owed();       // (last twice in a row: announce the earlier refill first)
+                    fill_slot(jj & 1, jj + 2, 0, 1);
+                    dma_pending = jj + 2;
+                }
             }
         }
     };
-    // after a drain: publish the previous unit, count this wave out of the layers it has moved past
-    auto settle = [&](int upto) {
-        if (prev_u >= 0) { if (lane == 0) lb[kDoneB + (prev_u - u_begin)] = (unsigned char)(prev_j + 1); prev_u = -1; }
-        if (dma_pending >= 0) { if (lane == 0) lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
-        for (; left_upto < upto; ++left_upto) leave_layer(left_upto);
-    };
-    auto give_up = [&](int code) {
-        if (lane == 0) {
-            __hip_atomic_store(p.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            ctl[1] = 1;
-        }
-        dead = true;
-    };
-    auto wait_deps = [&](const Deps& q, unsigned mask, int code) {
-        for (int k = 0; k < kSpinLimit; ++k) {
-            const unsigned bad = eval(q) & mask;
-            if (!bad) return;
-            if (*(volatile int*)&ctl[1]) { dead = true; return; }
-            if ((bad & 0x6u) && q.needL) poll_finish(0, poll_issue(0), q.needL);
-            if ((bad & 0x30u) && q.needR) poll_finish(1, poll_issue(1), q.needR);
+    // bounded wait for the dependencies `mask` of task (j, u) (rare: everything a task needs is normally a layer old);
+    // `lv` = the layer vpack describes on entry and again on return
+    auto wait_deps = [&](int j, int u, unsigned mask, int lv, int code) {
+        // never spin while holding unpublished work -- and "work" includes leaving the layers this wave has moved past: with few
+        // units per workgroup a wave's next task can be two layers on, and the weights it then waits for are refilled by the
+        // LAST wave to leave the layer it has just finished
+        flush_owed();
+        leave_layers(j);
+        if (dma_pending >= 0) flush_owed();
+        if (lv != j) layer_vectors(j);
+        const int addr = dep_addr(j, u);
+        bool ok = false;
+        for (int k = 0; k < kSpinLimit && !ok; ++k) {
+            const unsigned bad = eval(addr) & mask;
+            if (!bad) { ok = true; break; }
+            if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1])) break;      // (readfirstlane: the loop must stay wave-uniform)
+            if ((bad & 0x6u) && __ballot(addr == kSeenLB && (lane == 1 || lane == 2))) poll_side(0, j);
+            if ((bad & 0x30u) && __ballot(addr == kSeenRB && (lane == 4 || lane == 5))) poll_side(1, j - 1);
             __builtin_amdgcn_s_sleep(4);
         }
-        give_up(code);
+        if (lv != j) layer_vectors(lv);
+        if (ok) return;
+        // (every lane stores the same words: a lane-0 branch here makes the compiler treat `dead`, and with it the whole
+        // task loop, as divergent -- scalar bookkeeping in VGPRs, a waterfall loop around every buffer access)
+        __hip_atomic_store(p.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *(__attribute__((address_space(3))) volatile int*)&ctl[1] = 1;
+        dead = true;
     };
 
     // ---- tasks: index i = layer * n + k, unit = u_end - 1 - k; claimed from the LDS counter one iteration ahead ---------
@@ -353,30 +349,34 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         return v;          // lane 0's value; readfirstlane at the point of use
     };
     auto locate = [&](int i, int& j) -> int {      // j: a layer at or before the task's (tasks are claimed in increasing order)
-        while (j < L && i >= (j + 1) * n) ++j;
+#pragma clang loop unroll(disable) vectorize(disable)
+        while (j < L && i >= (j + 1) * n) ++j;      // (normally zero or one step: keep it a three-instruction scalar loop)
         return j < L ? u_end - 1 - (i - j * n) : -1;
     };
     int j = 0;
     int u = locate(__builtin_amdgcn_readfirstlane(claim()), j);
     int claim_v = claim();                 // the task after that
     float rxb[32], rxc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
-    bool war_ok = true, need_load = true;       // need_load: the rows of the task in hand were NOT prefetched
-    Deps curd{};
-    if (u >= 0) {
-        curd = deps_of(j, u);
-        war_ok = (eval(curd) & kWarMask) == 0;
-    }
+    bool war_ok = true;                    // (of the task in hand; its RAW side is satisfied when it starts)
     PT_DECL
 #ifdef PWV_PTRACE
     const long long pt_start = __builtin_amdgcn_s_memtime();
     const long long pt_start_rt = __builtin_amdgcn_s_memrealtime();
     pt_acc[7] = pt_start;
 #endif
+    if (u >= 0) {
+        // the first task: nothing was prefetched
+        leave_layers(j);
+        layer_vectors(j);
+        const unsigned bad = eval(dep_addr(j, u));
+        if (bad & kRawMask) wait_deps(j, u, kRawMask, j, 4);
+        war_ok = (bad & kWarMask) == 0;
+        if (!dead) load_x(j, u, rxb, rxc);
+    }
+    int lv_j = j;                          // layer voff / vneed currently describe
 
     while (u >= 0 && !dead) {
-        // ---- TOP: P row and the next task's flags are requested; the rows of this unit were prefetched ---------------------
+        // ---- TOP: P row requested; the rows of this unit were requested during the previous one ---------------------------
         int row, rc, nn, t;
         bool valid;
         unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
@@ -394,80 +394,53 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                 }
         }
+        // the next task (claimed an iteration ago) and the bytes it depends on
         int j2 = j;
-        const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);      // claimed an iteration ago
-        Deps nxt{};
-        unsigned bad2 = ~0u;
-        int pvL = 0, pvR = 0;
-        bool polledL = false, polledR = false;
+        const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);
+        unsigned bad2 = 0;                     // its dependency bits (one LDS byte per lane, read here under the P loads)
         if (u2 >= 0) {
-            nxt = deps_of(j2, u2);
-            bad2 = eval(nxt);
-            // a neighbour's progress is behind what the next task needs, as far as this workgroup has looked: look again
-            polledL = (bad2 & 0x6u) && nxt.needL;
-            polledR = (bad2 & 0x30u) && nxt.needR;
-            if (polledL) pvL = poll_issue(0);
-            if (polledR) pvR = poll_issue(1);
-        }
-        if (need_load) {
-            // rows not prefetched (first task, or their producers were not done when the previous iteration looked): publish
-            // everything this wave owes FIRST -- a wave never spins while it holds unpublished work -- then wait, then load
-            PT_ADD(6, 1);
-            PT_BEGIN();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            settle(j);
-            if (dma_pending >= 0) flush_owed();
-            wait_deps(curd, kRawMask, 4);
-            PT_END(2);
-            if (dead) break;
-            load_x(j, u, rxb, rxc);
+            if (j2 != lv_j) { layer_vectors(j2); lv_j = j2; }
+            bad2 = eval(dep_addr(j2, u2));
         }
 
         const float* bias = lds + kBiasF + (j & 1) * 64 + h * 32;
         float o[32];
         f32x16 acc2[2];
-        // the next task's rows: requested between GEMM1 and GEMM2, in flight under GEMM2 + gating + stores
-        bool raw_ok2 = false, war_ok2 = false;
+        // drain + publish + leave, behind the first operand work of the unit (the P row and the previous unit's stores land
+        // meanwhile); then the verdict on the next task's dependencies
+        auto settle_top = [&]() {
+            PT_BEGIN();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PT_END(1);
+            publish();
+            if (left_upto < j) leave_layers(j);
+            if (u2 >= 0) claim_v = claim();
+            PT_ADD(5, 1);
+        };
+        // the next task's rows: requested between GEMM1 and GEMM2, in flight under GEMM2 + gating + stores -- if their
+        // producers are done (normally they are a layer-sweep old); otherwise behind this unit's stores, after a wait
         auto prefetch_next = [&]() {
-            if (u2 >= 0 && raw_ok2) {
+            if (u2 >= 0 && !(bad2 & kRawMask)) {
                 load_x(j2, u2, rxb, rxc);
-            } else {      // nothing prefetched: last task of this wave, or the next task's producers are still at work
+            } else {      // (ends the old rows' live ranges: without it they would occupy 64 registers through both GEMMs)
 #pragma unroll
                 for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
             }
             __builtin_amdgcn_sched_barrier(0);
-        };
-        // drain + publish + leave, behind the first operand work of the unit (the P row and the previous unit's stores land
-        // meanwhile); then the verdict on the next task's dependencies
-        auto settle_top = [&]() {
-            if (!need_load) {
-                PT_BEGIN();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                PT_END(1);
-                PT_BEGIN();
-                settle(j);
-                PT_END(4);
-            }
-            if (polledL) poll_finish(0, pvL, nxt.needL);
-            if (polledR) poll_finish(1, pvR, nxt.needR);
-            if (u2 >= 0) {
-                if (polledL || polledR) bad2 = eval(nxt);
-                claim_v = claim();
-            }
-            raw_ok2 = (bad2 & kRawMask) == 0;
-            war_ok2 = (bad2 & kWarMask) == 0;
-            PT_ADD(5, 1);
         };
         // the last fragment of the dense matrix (not in LDS): global memory, 16 bytes per lane
         const float* lastfrag = packed_n + (size_t)j * p.packed_stride + kSlot + lane * 4;
 
         if constexpr (F32) {
             // ---- exact-fp32 arithmetic: v_mfma_f32_32x32x2_f32, the operands are the rows as loaded (pwv_layer.hip) ----
+            float xc[32], xb[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { xc[k] = rxc[k]; xb[k] = rxb[k]; }
             settle_top();
             const float* Af = lds + (j & 1) * kSlot;                 // [kA1 | kA2 minus its last fragment]
             f32x4 a[4];
             f32x4 lf = {0.f, 0.f, 0.f, 0.f};
-            auto bx = [&](int ks) -> float { return ks < 32 ? rxb[ks] : rxc[ks - 32]; };
+            auto bx = [&](int ks) -> float { return ks < 32 ? xb[ks] : xc[ks - 32]; };
             a[0] = frag(Af, 0, 0, 16, 0, lane);
             a[1] = frag(Af, 0, 2, 16, 0, lane);
             gemm_groups<16, 2, 0, 2>(Af, 0, lane, acc, a, bx, [](int) {}, [&](f32x4(&nf)[4]) {
@@ -491,7 +464,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bd = *reinterpret_cast<const f32x4*>(bias + it * 16 + q * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = rxc[it * 16 + q * 4 + e] + bd[e];
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bd[e];
                 }
             asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(lf));
             prefetch_next();
@@ -574,16 +547,16 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     }
                 });
         }
+        if (dead) break;
         // ---- stores (after the readers of the ring slot they overwrite are known to be done) -------------------------------
         if (!war_ok) {
             PT_BEGIN();
-            flush_owed();
-            wait_deps(curd, kWarMask, 5);
+            wait_deps(j, u, kWarMask, lv_j, 5);
             PT_END(3);
             if (dead) break;
         }
         {
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc(ring_of(mod3(j + p.rot)));
+            const int so = out_soff(j);
             const int oo = toff(row);
             // units the right neighbour reads as x[t-d] in the next layer are stored write-through
             const int dn = dil_of(j + 1 < L ? j + 1 : j);
@@ -594,14 +567,14 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     for (int g = 0; g < 8; ++g) {
                         const int it = g >> 2, q = g & 3;
                         const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, kAuxWriteThrough);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ring_rs, oo + g * 1024, so, kAuxWriteThrough);
                     }
                 } else {
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         const int it = g >> 2, q = g & 3;
                         const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, oo + g * 1024, 0, PWV_PERSIST_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ring_rs, oo + g * 1024, so, PWV_PERSIST_STORE_AUX);
                     }
                 }
             }
@@ -609,17 +582,27 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- move on ------------------------------------------------------------------------------------------------------
-        prev_u = u;
+        prev_addr = kDoneB + (u - u_begin);
         prev_j = j;
-        j = j2; u = u2;
-        war_ok = war_ok2;
-        need_load = !raw_ok2;
-        curd = nxt;
+        if (u2 >= 0 && (bad2 & kRawMask)) {
+            // the next task's producers were still at work when this unit looked: publish what this wave owes (a wave never
+            // spins while holding unpublished work), wait, then load with the latency exposed
+            PT_BEGIN();
+            PT_ADD(6, 1);
+            wait_deps(j2, u2, kRawMask, lv_j, 4);
+            PT_END(2);
+            if (dead) break;
+            load_x(j2, u2, rxb, rxc);
+        }
+        j = j2;
+        u = u2;
+        war_ok = (bad2 & kWarMask) == 0;
     }
     // the last unit's stores, a refill this wave still owes, and the layers it has not yet counted itself out of
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!dead) {
-        settle(L);
+        publish();
+        leave_layers(L);
         if (dma_pending >= 0) flush_owed();
     }
 #ifdef PWV_PTRACE

@@ -65,7 +65,15 @@ PERSIST_AUTO_MAX_ROWS = int(os.environ.get('PWV_PERSIST_AUTO_MAX_ROWS', '72000')
 PERSIST_MIN_UNITS = int(os.environ.get('PWV_PERSIST_MIN_UNITS', '0'))
 # longest run of layers in one persistent launch (a stack's residual layers are cut into equal runs that hand the ring on)
 PERSIST_MAX_LAYERS = int(os.environ.get('PWV_PERSIST_MAX_LAYERS', '32'))
+# The two nets of a flow run as two launch chains on two streams.  With CHAIN_FLOWS the chains stay on their streams ACROSS
+# the flows of a forward: each evaluates the IAF affine for itself and meets the other through two words of device memory
+# (pwv_iaf_affine_sync_f32) instead of a stream-level join + fork per flow (~50 us per flow boundary on a two-queue HIP graph).
+# PWV_CHAIN_FLOWS=0 restores the joins (A/B knob; also the fallback after a wait ran into its bound).
+CHAIN_FLOWS = os.environ.get('PWV_CHAIN_FLOWS', '0') != '0'
+CHAIN_SKEW_US = int(os.environ.get('PWV_CHAIN_SKEW_US', '0'))      # chain 1 leaves every flow boundary this much behind chain 0
+CHAIN_FORWARDS = 0        # forwards that took run_flow_chain (tests / tools look at it)
 _persist_status_addr = None
+_sync_status_addr = None
 _side_streams = {}
 
 
@@ -90,6 +98,27 @@ def raise_if_persist_failed() -> None:
         PERSIST = False
         raise _lib.PwvPersistError('the persistent stack kernel gave up (code %d); its outputs are invalid -- the per-layer path '
                                    'is used from now on, rerun the forward' % code)
+
+
+def sync_status() -> int:
+    """The library's sticky status word of the two-chain handshake (pinned host memory): 0, or != 0 once a wait for the other
+    chain ran into its bound (the chains were not running concurrently); that forward's outputs are invalid."""
+    global _sync_status_addr
+    if _sync_status_addr is None:
+        p = c_void_p()
+        check(_lib.lib().pwv_sync_status(ctypes.byref(p)), 'pwv_sync_status')
+        _sync_status_addr = p.value
+    return ctypes.c_int.from_address(_sync_status_addr).value
+
+
+def raise_if_sync_failed() -> None:
+    global CHAIN_FLOWS
+    if _sync_status_addr is not None and sync_status() != 0:
+        ctypes.c_int.from_address(_sync_status_addr).value = 0
+        CHAIN_FLOWS = False
+        raise _lib.PwvPersistError('a launch chain waited for the other one in vain (the two streams were not running concurrently, '
+                                   'e.g. under a profiler that serialises kernels); the outputs are invalid -- stream-level joins are '
+                                   'used from now on, rerun the forward')
 
 
 def _persist_runs(L: int) -> List[Tuple[int, int]]:
@@ -524,17 +553,23 @@ def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
     if not HOIST_P or not isinstance(cond, RepeatedCondition) or not nets:
         return
     prec = PRECISIONS[precision or DEFAULT_PRECISION]
-    plans = []
-    for net in nets:
-        if not getattr(net, 'fused_supported', None) or not net.fused_supported(cond):
-            continue
-        if cond.frames.shape[2] != net.condition_channels:
-            continue
-        p = get_plan(net, 'frames', prec)
-        if prec == _lib.PREC_F16X3 and not (p.f16x3_ok and p.x_limit > 0):
-            continue
-        if all(p is not q for q in plans):
-            plans.append(p)
+    for _ in range(2):
+        # (a first forward creates its variables while the plans are built, and every new variable outdates the plans
+        # made before it: plan again once the store has stopped changing, so that run_nets finds these very plans)
+        versions = [net.store.version for net in nets]
+        plans = []
+        for net in nets:
+            if not getattr(net, 'fused_supported', None) or not net.fused_supported(cond):
+                continue
+            if cond.frames.shape[2] != net.condition_channels:
+                continue
+            p = get_plan(net, 'frames', prec)
+            if prec == _lib.PREC_F16X3 and not (p.f16x3_ok and p.x_limit > 0):
+                continue
+            if all(p is not q for q in plans):
+                plans.append(p)
+        if versions == [net.store.version for net in nets]:
+            break
     if len(plans) < 2:
         return
     key = tuple(id(p) for p in plans)
@@ -553,6 +588,111 @@ def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
     f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames, c)
     p_all = linear_op(f2d, w_all, b_all, relu=False, precision=precision or DEFAULT_PRECISION)
     cond.proj_bank = {id(p): p_all[:, o:o + p.proj_w.shape[1]] for p, o in zip(plans, offs)}
+
+
+def run_flow_chain(flow_nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None) -> Optional[torch.Tensor]:
+    """All flows of a forward (flow_nets = [(scalar net, shifter net), ...], models.py:34-70) with the two nets' launch chains
+    kept on their two streams from the first flow to the last: ONE fork, ONE join, and per flow boundary one small launch per
+    chain that meets the other chain through device memory and evaluates x' = x * s + b (modules.py:59) into the chain's own copy
+    of x.  Bit-identical to the per-flow form (same kernels, same operations).  Returns None when the forward is not of the shape
+    this covers (the caller then loops over the flows with run_nets): two-stream per-layer launches, scalar nets with the causal
+    layer rebuilt by layer 0, frame-rate or no condition with the hoisted projection bank, no skip accumulation."""
+    lib = _lib.lib()
+    prec = PRECISIONS[precision or DEFAULT_PRECISION]
+    if not (CHAIN_FLOWS and TWO_STREAMS and FUSE_FIRST and len(flow_nets) >= 2 and prec in (_lib.PREC_F16X3, _lib.PREC_F32)):
+        return None
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[2] == 1 and x.numel() > 0):
+        return None
+    x = _require_cuda_f32(x, 'input_batch')
+    n, t, _ = x.shape
+    if cond is None:
+        mode, hop, offset, frames_per_utt = 'none', 0, 0, 0
+    elif isinstance(cond, RepeatedCondition) and cond.length == t and cond.frames.shape[0] == n:
+        mode, hop, offset, frames_per_utt = 'frames', cond.hop, cond.offset, cond.frames.shape[1]
+    else:
+        return None
+    bank = getattr(cond, 'proj_bank', None) if mode == 'frames' else None
+    flows = []
+    for nets in flow_nets:
+        sc, sh = nets
+        for net in nets:
+            if not (getattr(net, 'fused_supported', None) and net.fused_supported(cond) and net.in_channels == 1 and net.out_channels == 1
+                    and net.filter_width == 2 and net.residual_channels == 64 and not net.use_skip_connection
+                    and (precision or DEFAULT_PRECISION) == (net.precision or precision or DEFAULT_PRECISION)):
+                return None
+            if mode == 'frames' and cond.frames.shape[2] != net.condition_channels:
+                return None
+        if not _same_structure(sc, sh) or len(sc.dilations) < 2 or _use_persist(2, n, t, sc.dilations):
+            return None
+        plans = [get_plan(net, mode, prec) for net in nets]
+        if any(p.causal_bias is not None for p in plans) or (prec == _lib.PREC_F16X3 and not all(p.f16x3_ok and p.x_limit > 0 for p in plans)):
+            return None
+        if mode == 'frames':
+            if bank is None or not all(id(p) in bank for p in plans):
+                return None
+            projs = [bank[id(p)] for p in plans]
+        else:
+            projs = [p.proj_b.reshape(1, -1) for p in plans]
+        flows.append((sc, plans, projs))
+    dev = x.device
+    rows = n * t
+    main = torch.cuda.current_stream()
+    side = _net_streams(dev)
+    # every buffer of the forward is allocated here and lives to the end of the function: nothing the chains still use can be
+    # handed out again by the allocator before the join below is on the main stream
+    bufs = [[torch.empty((lib.pwv_tile32_floats(rows, 64),), dtype=torch.float32, device=dev) for _ in range(2)] for _ in range(2)]
+    flags = torch.zeros((len(flows) * 2 * 32,), dtype=torch.int32, device=dev)      # one 128-byte line per (flow, chain)
+    keep = []
+    for g in range(2):
+        side[g].wait_stream(main)
+    streams = (c_void_p * 2)(side[0].cuda_stream, side[1].cuda_stream)
+    xg = [x, x]
+    for i, (net0, plans, projs) in enumerate(flows):
+        L = plans[0].n_layers
+        outs = [torch.empty((n, t, 1), dtype=torch.float32, device=dev) for _ in range(2)]
+        sa = StackArgs()
+        sa.G, sa.n_layers = 2, L
+        dil = (ctypes.c_int * L)(*[int(d) for d in net0.dilations])
+        sa.dilations = dil
+        for g in range(2):
+            sa.buf0[g], sa.buf1[g] = bufs[g][0].data_ptr(), bufs[g][1].data_ptr()
+            sa.packed_layers[g] = plans[g].packed_layers.data_ptr()
+            sa.proj[g] = projs[g].data_ptr()
+            sa.packed_head[g] = plans[g].packed_head.data_ptr()
+            sa.out[g] = outs[g].data_ptr()
+            sa.causal_filter[g] = plans[g].causal_filter.data_ptr()
+        sa.packed_layer_stride = plans[0].layer_floats
+        sa.proj_row_stride = projs[0].stride(0) if mode == 'frames' else 128 * L
+        sa.Q, sa.N, sa.T = 1, n, t
+        sa.cond_hop, sa.cond_offset, sa.cond_frames = hop, offset, frames_per_utt
+        sa.precision = prec
+        sa.separate_head = 0 if FUSE_HEAD else 1
+        sa.x_first, sa.x_first_chain1 = _ptr(xg[0]), _ptr(xg[1])
+        sa.x_limit = min(p.x_limit for p in plans)
+        sa.range_flag = range_flag_ptr()
+        evs = []
+        if EVENT_LOG is not None and L > 1:      # bench.py's live kernel timing (see run_nets)
+            for c in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side[c])
+                e1.record(side[c])
+                sa.ev_begin[c], sa.ev_end[c] = e0.cuda_event, e1.cuda_event
+                evs.append((e0, e1))
+        check(lib.pwv_wavenet_stack_f32(ctypes.byref(sa), streams), 'pwv_wavenet_stack_f32')
+        for e0, e1 in evs:
+            EVENT_LOG.append(('layer_residual', e0, e1, 1, L - 1))
+        newx = [torch.empty((n, t, 1), dtype=torch.float32, device=dev) for _ in range(2)]
+        for g in range(2):
+            mine, other = flags.data_ptr() + 4 * 32 * (2 * i + g), flags.data_ptr() + 4 * 32 * (2 * i + 1 - g)
+            check(lib.pwv_iaf_affine_sync_f32(_ptr(xg[g]), _ptr(outs[0]), _ptr(outs[1]), 1, _ptr(newx[g]), rows, mine, other, CHAIN_SKEW_US if g == 1 else 0,
+                                              c_void_p(side[g].cuda_stream)), 'pwv_iaf_affine_sync_f32')
+        keep.append((outs, xg, dil))
+        xg = newx
+    for g in range(2):
+        main.wait_stream(side[g])
+    global CHAIN_FORWARDS
+    CHAIN_FORWARDS += 1
+    return xg[0]
 
 
 def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,

@@ -53,6 +53,7 @@ class IAFVocoder(object):
         store = self.store or get_default_store()
         engine.raise_if_range_flag('an earlier call')       # sticky flags of forwards that have completed since
         engine.raise_if_persist_failed()
+        engine.raise_if_sync_failed()
         melspec = engine._require_cuda_f32(melspec, 'melspec')
         if melspec.dim() != 3 or melspec.shape[1] != self.t_mel or melspec.shape[2] != hp.signal.n_mels:
             raise ValueError('melspec must be [N, %d, %d], got %s' % (self.t_mel, hp.signal.n_mels, tuple(melspec.shape)))
@@ -100,6 +101,13 @@ class IAFVocoder(object):
                     flows.append(iaf)
             # the frame-rate projections of every net depend on the mel only: one GEMM for all flows, ahead of the first
             engine.project_all([net for iaf in flows for net in iaf.nets()], condition, precision=self.precision)
+            # the common shape (two scalar nets per flow, no normaliser between the flows): the two nets' launch chains stay
+            # on their streams across the flows (engine.run_flow_chain); otherwise flow by flow
+            chained = None
+            if not shared and not hp.model.normalize:
+                chained = engine.run_flow_chain([iaf.nets() for iaf in flows], input, condition, precision=self.precision)
+            if chained is not None:
+                return chained
             for i, iaf in enumerate(flows):
                 input = iaf(input, condition)  # (n, t, h)
                 # normalization (identity at the default hparams), models.py:70
@@ -112,6 +120,7 @@ class IAFVocoder(object):
         import torch
         torch.cuda.synchronize()
         engine.raise_if_persist_failed()
+        engine.raise_if_sync_failed()
         engine.raise_if_range_flag()
 
     def _mel_limit(self, weights, store):
