@@ -53,14 +53,13 @@ FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
 # PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
 FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
 # The residual layers 1 .. L-2 of a stack as ONE persistent launch (csrc/pwv_stack_persist.hip, bit-identical results)
-# instead of one launch per layer.  PWV_PERSIST = 0 | 1 | auto (default).  Measured on MI355X: at the
-# headline size (160000 rows) both forms sit at the package power cap and deliver the same samples per joule (+-1.5 %
-# between boxes), while on short inputs -- where the per-layer launches are bound by their prologues, tails and gaps, not by
-# power -- the persistent launch wins (default model, 16000 samples, graph replay: 0.80 -> 0.64 ms; 64000: -2.7 %).
-# 'auto' therefore takes it up to PERSIST_AUTO_MAX_ROWS rows per launch and the two-stream per-layer launches above.
+# instead of one launch per layer.  PWV_PERSIST = 0 | 1 | auto (default).  Measured on MI355X under HIP-graph replay
+# (same box, alternating runs): headline C3 2.86 vs 3.02 ms per step, C2 1.57 vs 1.72 ms, C4 share 9.20 vs
+# 9.33 ms, C1 0.119 vs 0.148 ms, default model at 16000 samples 0.64 vs 0.80 ms, exact fp32 6.80 vs 6.94 ms.
+# 'auto' takes it wherever the library supports the shape (up to PERSIST_AUTO_MAX_ROWS rows per launch); '1' forces it.
 _pm = os.environ.get('PWV_PERSIST', 'auto')
 PERSIST = {'0': False, '1': True}.get(_pm, 'auto')
-PERSIST_AUTO_MAX_ROWS = int(os.environ.get('PWV_PERSIST_AUTO_MAX_ROWS', '72000'))
+PERSIST_AUTO_MAX_ROWS = int(os.environ.get('PWV_PERSIST_AUTO_MAX_ROWS', str(1 << 30)))
 # short inputs: fewer workgroups rather than ranges below this many units (0 = the library's default, 4)
 PERSIST_MIN_UNITS = int(os.environ.get('PWV_PERSIST_MIN_UNITS', '0'))
 # longest run of layers in one persistent launch (a stack's residual layers are cut into equal runs that hand the ring on)

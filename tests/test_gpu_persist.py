@@ -125,14 +125,20 @@ def test_persistent_give_up_is_loud_and_falls_back(gpu, persist_knobs):
     assert engine.PERSIST is False and engine.persist_status() == 0
 
 
-def test_auto_policy_takes_the_persistent_launch_for_short_inputs_only(gpu, persist_knobs):
-    """PWV_PERSIST=auto (the default): the persistent launch up to PERSIST_AUTO_MAX_ROWS rows per launch (where it wins),
-    the two-stream per-layer launches above (parity at the power cap); shapes the library refuses (here: a
-    look-back over more neighbours than one wave instruction polls) silently take the per-layer path."""
+def test_auto_policy_takes_the_persistent_launch_where_the_library_supports_the_shape(gpu, persist_knobs):
+    """PWV_PERSIST=auto (the default): the persistent launch wherever the library supports the shape, up to
+    PERSIST_AUTO_MAX_ROWS rows per launch; shapes it refuses (stacks of fewer than four layers; a look-back over more
+    neighbours than one wave instruction polls) silently take the per-layer path."""
     engine = persist_knobs
     engine.PERSIST = 'auto'
-    assert engine._use_persist(2, 1, 16000, D10) and engine._use_persist(1, 3, 16000, D10 * 3)
-    assert not engine._use_persist(2, 1, 160000, D10) and not engine._use_persist(2, 1, 16000, D10[:3])
+    assert engine._use_persist(2, 1, 16000, D10) and engine._use_persist(1, 3, 16000, D10 * 3) and engine._use_persist(2, 1, 160000, D10)
+    assert not engine._use_persist(2, 1, 16000, D10[:3])
+    saved = engine.PERSIST_AUTO_MAX_ROWS
+    engine.PERSIST_AUTO_MAX_ROWS = 72000
+    try:
+        assert engine._use_persist(2, 1, 64000, D10) and not engine._use_persist(2, 1, 160000, D10)
+    finally:
+        engine.PERSIST_AUTO_MAX_ROWS = saved
     engine.PERSIST, engine.PERSIST_MIN_UNITS = True, 1
     assert engine._use_persist(2, 1, 160000, D10)
     assert not engine._use_persist(2, 1, 3200, [1, 2, 4, 4096, 8, 16])       # 129 units back at one unit per workgroup
