@@ -416,6 +416,12 @@ typedef struct pwv_persist_args {
     int precision;                                /* PWV_PREC_F16X3 or PWV_PREC_F32 (packed_layers packed accordingly) */
     int max_workgroups;                           /* 0 = one per CU */
     int min_units_per_workgroup;                  /* short inputs: use fewer workgroups rather than ranges below this (0 = 4) */
+    /* optional: the run starts with the net's layer 0, which evaluates the causal layer itself from the scalar input [N*T]
+     * (pwv_layer_args.x_first: same operations, same bits); buffer (2 + r) % 3 is then not read */
+    const float* x_first;
+    const float* causal_filter[PWV_MAX_NETS];
+    float x_limit;                                /* range guard on x_first (pwv_layer_args.x_limit / range_flag) */
+    int* range_flag;
 } pwv_persist_args;
 
 size_t pwv_persist_workspace_bytes(const pwv_persist_args* args);

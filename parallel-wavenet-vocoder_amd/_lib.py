@@ -142,6 +142,10 @@ class PersistArgs(Structure):
         ('precision', c_int),
         ('max_workgroups', c_int),
         ('min_units_per_workgroup', c_int),
+        ('x_first', c_void_p),
+        ('causal_filter', c_void_p * PWV_MAX_NETS),
+        ('x_limit', ctypes.c_float),
+        ('range_flag', c_void_p),
     ]
 
 

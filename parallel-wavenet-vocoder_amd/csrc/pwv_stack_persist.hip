@@ -47,8 +47,9 @@ constexpr int kBiasF = 2 * kSlot;              // [2 slots][64] dense bias
 constexpr int kCtlF = kBiasF + 128;            // control ints: [0] task counter, [1] abort, [2..3] flag bytes, [8 + j] waves that left layer j
 constexpr int kCtlInts = 40;
 constexpr int kLdsFloats = 40960;              // all 160 KB of the CU
-constexpr int kDoneB = (kCtlF + kCtlInts) * 4;             // byte offset of the per-unit "layers completed" bytes
-constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 1376 units per workgroup
+constexpr int kCfF = kCtlF + kCtlInts;       // causal filter [2][64] (a run that starts with the net's layer 0, see x_first)
+constexpr int kDoneB = (kCfF + 128) * 4;                   // byte offset of the per-unit "layers completed" bytes
+constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 864 units per workgroup
 constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
 constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
 constexpr int kMaxPLayers = 32;
@@ -69,6 +70,10 @@ struct PersistParams {
     int cond_hop, cond_offset, cond_frames;
     unsigned T_magic, T_shift, hop_magic, hop_shift;
     int dil[kMaxPLayers];
+    const float* x_first;                  // != NULL: the run starts with the net's layer 0, which rebuilds the causal layer from the scalar input
+    const float* cfilt[PWV_MAX_NETS];      // ... and each net's causal filter [2,1,64]
+    float x_limit;                         // range guard of the split-fp16 arithmetic on x_first (include/pwv_hip.h)
+    int* range_flag;
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
 };
 
@@ -205,10 +210,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         if (first == 0 && lane < 16)      // dense bias [2 h][32]
             __builtin_amdgcn_global_load_lds((gptr_t)(src + kSlotFull), (lptr_t)(lds + kBiasF + slot * 64), 16, 0, 0);
     };
+    if (p.x_first && tid < 128) lds[kCfF + tid] = p.cfilt[net][tid];
     fill_slot(0, 0, wave, 8);
     if (L > 1) fill_slot(1, 1, wave, 8);
     __syncthreads();
+#ifndef PWV_PERSIST_NOPRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // ONE buffer descriptor for the three ring buffers (they are one allocation); the buffer of a layer is selected by the
     // scalar offset operand of the load / store.  sc1 loads: L2-served, never the CU's L1.
@@ -228,9 +236,21 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         int row, rc, nn, t;
         bool valid;
         unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
-        const int so = in_soff(j);
         const int d = dil_of(j);
         const bool has_prev = t >= d;
+        if (p.x_first && j == 0) {
+            // layer 0 of the net: the four scalars its two rows are functions of (x[t], x[t-1], x[t-d], x[t-d-1]; zero left of
+            // the utterance start); rebuilt into rows at the top of the unit (layer_f16x3_kernel's FIRST variant)
+            const float* x1 = p.x_first;
+            xc[0] = x1[rc];
+            xc[1] = t >= 1 ? x1[rc - (t >= 1 ? 1 : 0)] : 0.f;
+            xb[0] = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f;
+            xb[1] = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
+#pragma unroll
+            for (int k = 2; k < 32; ++k) xb[k] = xc[k] = 0.f;      // (every element written on every path: the arrays stay in registers)
+            return;
+        }
+        const int so = in_soff(j);
         const int oc = toff(rc), ob = toff(has_prev ? rc - d : rc);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -403,6 +423,24 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             bad2 = eval(dep_addr(j2, u2));
         }
 
+        if (p.x_first && j == 0) {
+            // rebuild this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; the operation order of
+            // iaf_front_kernel / the FIRST variant of the per-layer kernel: round(x[t-1] w0), then fma(x[t], w1, .)
+            const float x0 = rxc[0], x1v = rxc[1], xd0 = rxb[0], xd1 = rxb[1];
+            const bool has_prev = t >= dil_of(0);
+            if (p.range_flag && !(fabsf(x0) <= p.x_limit)) __hip_atomic_store(p.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCfF + 8 * g + 4 * h]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&lds[kCfF + 64 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rxc[4 * g + e] = fmaf(x0, w1[e], x1v * w0[e]);
+                    const float vb = fmaf(xd0, w1[e], xd1 * w0[e]);
+                    rxb[4 * g + e] = has_prev ? vb : 0.f;
+                }
+            }
+        }
         const float* bias = lds + kBiasF + (j & 1) * 64 + h * 32;
         float o[32];
         f32x16 acc2[2];
@@ -728,6 +766,15 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     make_magic((unsigned)a->T, p.T_magic, p.T_shift);
     make_magic((unsigned)(a->cond_hop > 0 ? a->cond_hop : 1), p.hop_magic, p.hop_shift);
     for (int j = 0; j < a->n_layers; ++j) p.dil[j] = a->dilations[j];
+    p.x_first = a->x_first;
+    if (a->x_first) {
+        for (int g = 0; g < a->G; ++g) {
+            PWV_CHECK_ARG(a->causal_filter[g], "pwv_wavenet_stack_persist_f32: x_first needs every net's causal filter");
+            p.cfilt[g] = a->causal_filter[g];
+        }
+        p.x_limit = a->x_limit;
+        p.range_flag = a->range_flag;
+    }
     p.trace = nullptr;
 #ifdef PWV_PTRACE
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }

@@ -120,11 +120,12 @@ def raise_if_sync_failed() -> None:
                                    'used from now on, rerun the forward')
 
 
-def _persist_runs(L: int) -> List[Tuple[int, int]]:
-    """(first layer, count) of the persistent launches that cover the residual layers 1 .. L-2."""
-    Lp = L - 2
+def _persist_runs(L: int, first: int = 1) -> List[Tuple[int, int]]:
+    """(first layer, count) of the persistent launches that cover the residual layers `first` .. L-2 (first = 0: layer 0
+    rebuilds the causal layer from the scalar input inside the launch, pwv_persist_args.x_first)."""
+    Lp = L - 1 - first
     nchunks = -(-Lp // max(2, PERSIST_MAX_LAYERS))
-    runs, j0 = [], 1
+    runs, j0 = [], first
     for c in range(nchunks):
         cnt = Lp // nchunks + (1 if c < Lp % nchunks else 0)
         runs.append((j0, cnt))
@@ -134,14 +135,14 @@ def _persist_runs(L: int) -> List[Tuple[int, int]]:
     return runs
 
 
-def _use_persist(G: int, n: int, t: int, dilations) -> bool:
+def _use_persist(G: int, n: int, t: int, dilations, first: int = 1) -> bool:
     L = len(dilations)
     if PERSIST is False or L < 4:
         return False
     if PERSIST == 'auto' and n * t > PERSIST_AUTO_MAX_ROWS:
         return False
     lib = _lib.lib()
-    for j0, cnt in _persist_runs(L):           # 0 bytes = the library cannot run this shape persistently: per-layer launches
+    for j0, cnt in _persist_runs(L, first):    # 0 bytes = the library cannot run this shape persistently: per-layer launches
         pa = _lib.PersistArgs()
         pa.G, pa.n_layers, pa.N, pa.T = G, cnt, n, t
         pa.dilations = (ctypes.c_int * cnt)(*[int(d) for d in dilations[j0:j0 + cnt]])
@@ -281,6 +282,18 @@ def logistic_noise_op(shape: Sequence[int], device, seed: int, offset: int = 0, 
     if out is not None and (tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous()):
         raise ValueError('out must be a contiguous float32 tensor of shape %s' % (tuple(shape),))
     check(_lib.lib().pwv_logistic_noise_f32(_ptr(z), z.numel(), seed, offset, _stream()), 'pwv_logistic_noise_f32')
+    return z
+
+
+def logistic_noise_window(n: int, total_length: int, first_sample: int, window: int, device, seed: int, first_item: int = 0) -> torch.Tensor:
+    """[n, window, 1] Logistic(0,1) noise for the samples [first_sample, first_sample + window) of the utterances
+    first_item .. first_item + n - 1 of ONE counter-based stream in which utterance i, sample t is counter
+    i * total_length + t: what a rank needs for its share of a sharded job (utterance shards: first_item = the rank's first
+    utterance; time shards: first_sample = the window's start) -- every rank draws exactly the values an unsharded run
+    with the same seed would have drawn there, with no communication."""
+    z = torch.empty((n, window, 1), dtype=torch.float32, device=device)
+    for i in range(n):
+        logistic_noise_op((1, window, 1), device, seed=seed, offset=(first_item + i) * total_length + first_sample, out=z[i:i + 1])
     return z
 
 
@@ -477,17 +490,14 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         la.precision = prec
         return la
 
-    la = layer_args(0, 0, 2)                # (src is the causal layer's buffer unless layer 0 rebuilds it from x_first)
-    la.out_mode = _lib.OUT_RESIDUAL
-    if x_first is not None:
-        la.x_first, la.x_limit, la.range_flag = _ptr(x_first), x_limit, range_flag_ptr()
-        for g in range(G):
-            la.causal_filter[g] = plans[g].causal_filter.data_ptr()
-    check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
+    if x_first is None:                     # layer 0 on the causal layer's buffer (bufs[g][0]) as a launch of its own
+        la = layer_args(0, 0, 2)
+        la.out_mode = _lib.OUT_RESIDUAL
+        check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
 
-    # the residual layers 1 .. L-2 as persistent launches of at most PERSIST_MAX_LAYERS layers each, handing the ring on
+    # the residual layers (0 or) 1 .. L-2 as persistent launches of at most PERSIST_MAX_LAYERS layers each, handing the ring on
     rot, out_slot = 0, 2
-    for j0, cnt in _persist_runs(L):
+    for j0, cnt in _persist_runs(L, 1 if x_first is None else 0):
         pa = _lib.PersistArgs()
         pa.G, pa.n_layers = G, cnt
         dil = (ctypes.c_int * cnt)(*[int(d) for d in net0.dilations[j0:j0 + cnt]])
@@ -499,6 +509,10 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         pa.ring_stride = bufs[0][0].numel()
         pa.ring_rotation = rot
         pa.min_units_per_workgroup = PERSIST_MIN_UNITS
+        if j0 == 0:                          # the net's layer 0 rebuilds the causal layer from the scalar input
+            pa.x_first, pa.x_limit, pa.range_flag = _ptr(x_first), x_limit, range_flag_ptr()
+            for g in range(G):
+                pa.causal_filter[g] = plans[g].causal_filter.data_ptr()
         pa.packed_layer_stride = stride
         pa.proj_row_stride = row_stride
         pa.N, pa.T = n, t
@@ -782,8 +796,12 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
     main = torch.cuda.current_stream()
     use_skip = bool(net0.use_skip_connection)
+    # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
+    # (pwv_layer_args.x_first), so the [rows, 64] front buffer is neither written nor read
+    first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32) and qin == 1 and net0.filter_width == 2
+                   and net0.residual_channels == 64 and not net0.use_skip_connection and plans[0].causal_bias is None)
     persist = ((prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
-               and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations))
+               and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1))
     two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
     row_stride = 128 * L
@@ -815,8 +833,6 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
         bufs = [[tile_buf(R, torch.float16 if half else torch.float32) for _ in range(2)] for _ in nets]
     # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
     # (pwv_layer_args.x_first), so the [rows, 64] front buffer is neither written nor read
-    first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32) and qin == 1 and net0.filter_width == 2 and R == 64
-                   and not net0.use_skip_connection and plans[0].causal_bias is None)
     if prec == _lib.PREC_F16X3 and not first_fused:
         range_check_op(x, x_limit)          # (layer 0 checks its scalar input itself when it rebuilds the causal layer)
     if first_fused:

@@ -82,6 +82,33 @@ def _load_mels(data_path, batch_size, length, device):
     return gt, torch.from_numpy(np.stack(mels)).to(device)
 
 
+def forward_over_ranks(mel, batch_size, length, device, make_model, noise_window, n_mels, hop, halo, group=None):
+    """The forward of a job started with one process per GPU (WORLD_SIZE > 1; the reference is single-device,
+    generate.py:47-49).  Rank 0 passes all mels [batch_size, t_mel, n_mels]; it gets all waveforms [batch_size, length, 1]
+    back (other ranks: None).  Utterances shard across the ranks (distributed.generate_sharded); a batch smaller than the
+    world shards in TIME instead, exactly (distributed.generate_time_sharded_ranks, halo = timeshard.chain_halo).  Every
+    rank draws its share of ONE logistic-noise stream -- utterance i, sample t is counter i * length + t -- so the result
+    does not depend on how the job was cut.
+      make_model(n, window) -> callable(mel [n, 1 + window/hop, n_mels], z [n, window, 1]) -> [n, window, 1]
+      noise_window(n, first_sample, window, first_item) -> z [n, window, 1]"""
+    import torch.distributed as dist
+    from .distributed import generate_sharded, generate_time_sharded_ranks, shard_bounds
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    models = {}
+
+    def model_for(n, window):
+        if (n, window) not in models:
+            models[(n, window)] = make_model(n, window)
+        return models[(n, window)]
+
+    if batch_size >= world:
+        lo, _ = shard_bounds(batch_size, world, rank)
+        return generate_sharded(lambda m, zz: model_for(m.shape[0], length)(m, noise_window(m.shape[0], 0, length, lo)),
+                                mel, (1 + length // hop, n_mels), length, device, group=group)
+    return generate_time_sharded_ranks(lambda m, zz, t0: model_for(m.shape[0], (m.shape[1] - 1) * hop)(m, noise_window(m.shape[0], t0, (m.shape[1] - 1) * hop, 0)),
+                                       mel, n_mels, length, hop, halo, device, group=group)
+
+
 def generate(case='default', ckpt=None, debug=False):
     '''
     :param case: experiment case name
@@ -91,11 +118,18 @@ def generate(case='default', ckpt=None, debug=False):
     hp.set_hparam_yaml(case)
     if not torch.cuda.is_available():
         raise RuntimeError('generate() needs an MI355X: the HIP path has no CPU fallback')
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))       # one process per GPU
     device = torch.device('cuda', torch.cuda.current_device())
     logdir = os.environ.get('PWV_LOGDIR', hp.logdir)
 
     store = reset_default_store(device=device)              # fresh "graph"
     batch_size, length = hp.generate.batch_size, hp.generate.length
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        # one process per GPU (torchrun): utterances -- or, for a batch smaller than the world, time slices -- shard over
+        # the ranks; rank 0 reads the inputs and writes the outputs
+        return _generate_over_ranks(store, batch_size, length, device, logdir, ckpt, debug)
     gt_wav, melspec = _load_mels(hp.data_path, batch_size, length, device)
 
     model = IAFVocoder(batch_size=batch_size, length=length, store=store)
@@ -140,7 +174,12 @@ def generate(case='default', ckpt=None, debug=False):
         ms = e0.elapsed_time(e1)
         print('forward: %.2f ms, %.3g samples/s (first call includes weight packing)' % (ms, batch_size * length / ms * 1e3))
     pred_wav = pred.cpu().numpy()
+    _write_outputs(pred_wav, logdir)
+    print('Done.')
+    return pred_wav
 
+
+def _write_outputs(pred_wav, logdir):
     try:
         os.makedirs(logdir, exist_ok=True)
         from scipy.io import wavfile
@@ -150,6 +189,48 @@ def generate(case='default', ckpt=None, debug=False):
         print('wrote %d waveform(s) to %s' % (pred_wav.shape[0], logdir))
     except OSError as e:
         print('could not write outputs to %s: %s' % (logdir, e))
+
+
+def _generate_over_ranks(store, batch_size, length, device, logdir, ckpt, debug):
+    """generate() under a launcher (WORLD_SIZE > 1): see forward_over_ranks."""
+    import torch.distributed as dist
+    from . import engine
+    from .timeshard import chain_halo
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if not dist.is_initialized():
+        dist.init_process_group(backend='nccl', device_id=device)      # 'nccl' IS RCCL on ROCm (xGMI)
+    rank = dist.get_rank()
+    hop, n_mels = hp.signal.hop_length, hp.signal.n_mels
+    melspec = _load_mels(hp.data_path, batch_size, length, device)[1] if rank == 0 else None
+    ckpt = '{}/{}'.format(logdir, ckpt) if ckpt else (_latest_checkpoint(logdir) if os.path.isdir(logdir) else None)
+    if ckpt:
+        store.load_checkpoint(ckpt, use_ema=bool(hp.train.use_ema))
+    elif rank == 0:
+        print('No checkpoint found at {}.'.format(logdir))
+    seed = torch.tensor([int(os.environ.get('PWV_NOISE_SEED') or int.from_bytes(os.urandom(7), 'little'))], dtype=torch.int64, device=device)
+    dist.broadcast(seed, src=0)                                         # one noise stream for the whole job
+    seed = int(seed.item())
+    halo = chain_halo(hp.model.dilations, hp.model.filter_width, hp.model.n_iaf, hop)
+    used = []
+
+    def make_model(n, window):
+        m = IAFVocoder(batch_size=n, length=window, store=store)
+        used.append(m)
+        return lambda mel, z: m(None, mel, is_training=False, z=z)
+
+    def noise_window(n, first_sample, window, first_item):
+        return engine.logistic_noise_window(n, length, first_sample, window, device, seed, first_item)
+
+    pred = forward_over_ranks(melspec, batch_size, length, device, make_model, noise_window, n_mels, hop, halo)
+    for m in used:
+        m.verify()
+    if ckpt and store.not_restored():
+        missing = store.not_restored()
+        raise KeyError('checkpoint %s does not hold %d of the model\'s %d variables: %s' % (ckpt, len(missing), len(store.vars), ', '.join(missing[:6])))
+    if rank != 0:
+        return None
+    pred_wav = pred.cpu().numpy()
+    _write_outputs(pred_wav, logdir)
     print('Done.')
     return pred_wav
 

@@ -31,18 +31,22 @@ class IAFVocoder(object):
         # object and a running offset so that every call -- eager or graph replay -- continues the same stream.  The
         # default seed is drawn from the OS (PWV_NOISE_SEED pins it); ranks of a sharded job get different seeds that way.
         self.noise_seed = None
-        self.noise_calls = 0
+        self.noise_offset = 0            # counters drawn so far (a running total: calls may differ in batch size)
 
-    def sample_noise(self, n, device, out=None, seed=None):
-        """[n, length, 1] Logistic(0,1) noise (models.py:32-33); consecutive calls draw consecutive counter ranges."""
+    def _seed(self, seed=None):
         import os
+        if seed is not None:
+            return int(seed)
         if self.noise_seed is None:
             env = os.environ.get('PWV_NOISE_SEED')
             self.noise_seed = int(env) if env else int.from_bytes(os.urandom(7), 'little')
+        return self.noise_seed
+
+    def sample_noise(self, n, device, out=None, seed=None):
+        """[n, length, 1] Logistic(0,1) noise (models.py:32-33); consecutive calls draw consecutive counter ranges."""
         numel = n * self.length
-        z = engine.logistic_noise_op((n, self.length, 1), device, seed=self.noise_seed if seed is None else seed,
-                                     offset=self.noise_calls * numel, out=out)
-        self.noise_calls += 1
+        z = engine.logistic_noise_op((n, self.length, 1), device, seed=self._seed(seed), offset=self.noise_offset, out=out)
+        self.noise_offset += numel
         return z
 
     # -- network (models.py:23-78) -------------------------------------------------------------------

@@ -73,8 +73,8 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
                 assert torch.equal(a, b)
     finally:
         engine.EVENT_LOG = None
-    runs = engine._persist_runs(L)
-    assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 2)      # it really was persistent
+    runs = engine._persist_runs(L, 0)       # (scalar-input nets: the launch starts with the net's layer 0)
+    assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 1)      # it really was persistent
 
 
 def test_whole_model_persistent_eager_and_graph_replay(gpu, persist_knobs):
