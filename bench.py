@@ -62,6 +62,9 @@ def parse_args():
                     help="GEMM arithmetic: f16x3 = 3-term split-fp16 MFMA, fp32 accumulate (default, fp32 parity); f32 = exact "
                          "fp32 MFMA; f16 = REDUCED PRECISION build extension (fp16 residual stream, BASELINE config 5) -- "
                          "never the headline number")
+    ap.add_argument('--shard', default='utterance', choices=['utterance', 'time'],
+                    help="N > 1: 'utterance' = every GPU its own utterance(s) (weak scaling, the default); 'time' = ONE set of utterances cut along "
+                         "the time axis with overlap-and-discard (exact, pwv_amd/timeshard.py): strong scaling of a long utterance (bench/c5)")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every launch from the host instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
@@ -218,6 +221,17 @@ def main():
     if args.case == 'bench/c4' and not args.utts:
         utts = max(1, hp.generate.batch_size // 8)       # 64 utterances over 8 GPUs: 8 per GPU
     hop, n_mels = hp.signal.hop_length, hp.signal.n_mels
+    job_length = length                  # samples per utterance of the JOB
+    time_shard = None
+    if args.shard == 'time':
+        # every rank computes its slice [a, b) of the time axis of the SAME utterance(s), preceded by the flow chain's look-back
+        # (recomputed and discarded): exact, no data-path collective; the job's work is fixed, so this is STRONG scaling
+        from pwv_amd.timeshard import chain_halo, shard_plan
+        halo = chain_halo(hp.model.dilations, hp.model.filter_width, hp.model.n_iaf, hop)
+        plan = shard_plan(length, world, halo, hop)
+        c0, a, b = plan[min(rank, len(plan) - 1)]
+        time_shard = {'halo': halo, 'window': b - c0, 'share': b - a, 'shards': len(plan)}
+        length = b - c0                  # what this rank's forward runs on
     t_mel = 1 + length // hop
     rows = utts * length
 
@@ -245,7 +259,7 @@ def main():
         # synthetic, seeded per rank: mel ~ U(-1,1); random-init weights (glorot + N(0,0.1) biases) so bias paths run
         store = VariableStore(device=dev, seed=2)
         model0 = IAFVocoder(batch_size=utts, length=length, store=store, precision=args.precision)
-        model0.noise_seed = 1 + rank
+        model0.noise_seed = 1 + (0 if time_shard else rank)
         model0(None, mel, is_training=False)            # creates the variables
         for name in list(store.vars):
             if store.vars[name].dim() == 1:
@@ -316,7 +330,25 @@ def main():
 
     # ---- utterance scatter / gather over the job's backend, once, outside the timed loop (N > 1) --------------------
     sharded = None
-    if dist is not None:
+    if dist is not None and time_shard is not None:
+        from pwv_amd.distributed import generate_time_sharded_ranks
+        coll_dev = torch.device('cpu') if dryrun else dev
+        jt = 1 + job_length // hop
+        full_mel = (torch.rand((utts, jt, n_mels), generator=torch.Generator().manual_seed(7)) * 2 - 1).to(coll_dev) if rank == 0 else None
+        if control:
+            fwd = lambda m, zz, t0: torch.zeros((m.shape[0], (m.shape[1] - 1) * hop, 1))
+        else:
+            def fwd(m, zz, t0):
+                win = (m.shape[1] - 1) * hop
+                net = model0 if win == length else IAFVocoder(batch_size=m.shape[0], length=win, store=store, precision=args.precision)
+                zw = engine.logistic_noise_window(m.shape[0], job_length, t0, win, dev, 4242)
+                return net(None, m.to(dev), is_training=False, z=zw).to(coll_dev)
+        wav = generate_time_sharded_ranks(fwd, full_mel, n_mels, job_length, hop, time_shard['halo'], coll_dev)
+        if rank == 0:
+            assert tuple(wav.shape) == (utts, job_length, 1) and bool(torch.isfinite(wav).all())
+            sharded = '%d utterance(s) x %d samples cut into %d time shards (look-back %d samples), generated, gathered on rank 0: ok' % (
+                utts, job_length, time_shard['shards'], time_shard['halo'])
+    elif dist is not None:
         from pwv_amd.distributed import generate_sharded
         total = utts * world
         coll_dev = torch.device('cpu') if dryrun else dev        # gloo (test hooks) scatters / gathers host tensors only
@@ -344,13 +376,14 @@ def main():
         log, engine.EVENT_LOG = engine.EVENT_LOG, None
         # entries: ('layer_residual', ...) one chain's run of `cnt` back-to-back per-layer launches between two HIP events;
         #          ('persist', ...) ONE persistent launch covering `cnt` layers of `gnets` nets
-        pers = [(ref.elapsed_time(e0), ref.elapsed_time(e1), cnt, gnets) for tag, e0, e1, gnets, cnt in log if tag == 'persist']
+        pers = [(ref.elapsed_time(en[1]), ref.elapsed_time(en[2]), en[4], en[3]) for en in log if en[0] == 'persist']
+        first_runs = sum(en[3] for en in log if en[0] == 'persist' and len(en) > 5 and en[5])      # net-layers that read 4 B instead of 256 B per sample
         chains = [(ref.elapsed_time(e0), ref.elapsed_time(e1), cnt, gnets) for tag, e0, e1, gnets, cnt in log if tag == 'layer_residual']
         if pers:
             total_ms = sum(e - b for b, e, _, _ in pers)
             timing = {'kind': 'persist', 'launches': len(pers), 'total_ms': total_ms, 'net_layers': sum(cnt * g for _, _, cnt, g in pers),
                       'launch_ms': [min(e - b for b, e, _, _ in pers), max(e - b for b, e, _, _ in pers)],
-                      'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3]}
+                      'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3], 'first_net_layers': first_runs}
         elif chains:
             busy = merged_length([(b, e) for b, e, _, _ in chains])
             total_ms = sum(e - b for b, e, _, _ in chains)
@@ -360,7 +393,8 @@ def main():
 
     if rank == 0:
         nets_per_flow = 1 if bool(hp.model.get('shared_nets', False)) else 2
-        total_samples = rows * n_gpus * args.steps
+        # utterance shards: every GPU its own rows (weak scaling); time shards: ONE job of utts x job_length samples (strong scaling)
+        total_samples = (utts * job_length if time_shard else rows * n_gpus) * args.steps
         value = total_samples / elapsed
         n_layers = sum(len(d) for d in hp.model.dilations[:hp.model.n_iaf])
         n_nets = hp.model.n_iaf * nets_per_flow
@@ -373,7 +407,7 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if time_shard else 'weak',
             'vs_baseline': None,
             'dtype': {'f32': 'f32', 'f16x3': 'f32 via 3-term split-fp16 MFMA (fp32 accumulate, fp32 storage)',
                       'f16': 'f16 (REDUCED PRECISION extension: fp16 residual stream + fp16 MFMA, fp32 accumulate)'}[args.precision],
@@ -390,7 +424,8 @@ def main():
                             % (args.case, hp.model.n_iaf, n_nets, n_layers * nets_per_flow, hp.model.cond_upsample_method,
                                utts, length, length / 16000.0, t_mel, n_mels, hop),
                 'case': args.case, 'utterances_per_gpu': utts, 'samples_per_utterance': length,
-                'parallelism': 'utterance-sharded x%d (no data-path collective)' % n_gpus,
+                'parallelism': ('time-sharded x%d: every GPU one slice of the SAME %d x %d samples plus %d samples of recomputed look-back (exact, no data-path collective)'
+                                % (n_gpus, utts, job_length, time_shard['halo'])) if time_shard else 'utterance-sharded x%d (no data-path collective)' % n_gpus,
                 'noise': 'logistic, sampled on device inside the step',
                 'launch': 'HIP graph replay of the forward (noise sampled by an eager kernel per step)' if graphed else 'host-enqueued launches',
             },
@@ -405,7 +440,8 @@ def main():
         layer_bytes = LAYER_BYTES_PER_SAMPLE // 2 if args.precision == 'f16' else LAYER_BYTES_PER_SAMPLE
         if timing is not None and timing['kind'] == 'persist':
             # the dominant kernel is the persistent stack kernel: one launch runs `layers` residual layers of both nets of a flow
-            alg_bytes = rows * timing['net_layers'] * layer_bytes          # over all timed launches
+            # over all timed launches; a run that starts with the net's layer 0 reads 4 B per sample there instead of a 256 B row
+            alg_bytes = rows * (timing['net_layers'] * layer_bytes - timing['first_net_layers'] * (layer_bytes // 2 - 4))
             alg_flop = rows * timing['net_layers'] * LAYER_FLOP_PER_SAMPLE
             ach_gbs = alg_bytes / (timing['total_ms'] * 1e-3) / 1e9
             ach_tf = alg_flop / (timing['total_ms'] * 1e-3) / 1e12
@@ -483,7 +519,7 @@ def main():
                                                  '-- DESIGN.md section 4, K1 item 6 and K1p')
                 result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
                                            'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
-        per_gpu = value / n_gpus
+        per_gpu = rows * args.steps / elapsed if time_shard else value / n_gpus      # (time shards: the samples a GPU actually computes, look-back included)
         result['model'] = {
             'note': 'whole-model algorithmic work per output sample (SURVEY.md section 8d "layer-streaming" model), per GPU',
             'alg_bytes_per_sample': mb, 'alg_flop_per_sample': mf,

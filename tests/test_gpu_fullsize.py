@@ -105,6 +105,32 @@ def test_c5_transposed_conv_60s_full_size(gpu, precision):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize('method', ['transposed_conv', 'repeat'])
+def test_c5_60s_in_eight_time_shards_is_bit_identical(gpu, method):
+    """SURVEY 8 f-3 at BASELINE config 5's size: the 60 s utterance (1 x 960000) cut into 8 time shards with the flow chain's
+    look-back (6160 samples) recomputed per shard and discarded is torch.equal to the unsharded forward -- what 8 GPUs
+    compute under `bench.py --case bench/c5 --gpus 8 --shard time` / generate() with WORLD_SIZE = 8, here tiled on one
+    GPU (pwv_amd/timeshard.py; 'repeat' runs the persistent stack launches, 'transposed_conv' the per-layer ones)."""
+    import torch
+    from pwv_amd.timeshard import chain_halo, generate_time_sharded, shard_plan, vocoder_forward_factory
+    cfg = O.ModelConfig(cond_upsample_method=method)
+    L = 960000
+    model, w, mel, z, mel_t, z_t = _model(gpu, cfg, 1, L)
+    want = model(None, mel_t, is_training=False, z=z_t).clone()
+    halo = chain_halo(cfg.dilations, cfg.filter_width, cfg.n_iaf, cfg.hop_length)
+    assert halo == HALO
+    got = generate_time_sharded(vocoder_forward_factory(model.store), mel_t, z_t, cfg.hop_length, halo, n_shards=8)
+    assert torch.equal(got, want)
+    plan = shard_plan(L, 8, halo, cfg.hop_length)
+    assert [b - a for _, a, b in plan] == [120000] * 8 and [a - c0 for c0, a, _ in plan] == [0] + [halo] * 7
+    # the pieces ranks 2 and 5 of an 8-rank job would return
+    for r in (2, 5):
+        piece = generate_time_sharded(vocoder_forward_factory(model.store), mel_t, z_t, cfg.hop_length, halo, n_shards=8, shard_ids=[r])
+        assert torch.equal(piece, want[:, plan[r][1]:plan[r][2]])
+    del model, want, got
+    torch.cuda.empty_cache()
+
+
 def test_c4_share_8_utterances_full_size(gpu):
     """BASELINE config 4, one GPU's share: 8 utterances x 64000 samples (default.yaml:47-48 batch semantics, every
     utterance exactly generate.length: data_load.py:45-50).  EVERY utterance's prefix against the oracle, the end of

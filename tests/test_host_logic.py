@@ -171,3 +171,24 @@ def test_bench_spawns_its_own_ranks_when_started_without_a_launcher():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
     assert 'scattered over 2 ranks' in out['sharded_generate'] and 'dryrun' in out
+
+
+def test_bench_time_sharded_mode_is_strong_scaling():
+    """`python bench.py --case bench/c5 --gpus 2 --shard time`: the 60 s utterance of BASELINE config 5 cut along the time axis
+    over the ranks (pwv_amd/timeshard.py); one job of fixed size, so the line says "strong" and `value` counts the job's
+    samples once.  Control-flow dry run (no kernels) over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PWV_BENCH_DRYRUN='control')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--case', 'bench/c5', '--gpus', '2', '--shard', 'time',
+                          '--steps', '2', '--warmup', '1'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong'
+    assert 'time-sharded x2' in out['config']['parallelism'] and '6160 samples' in out['config']['parallelism']
+    assert 'cut into 2 time shards' in out['sharded_generate']
+    assert abs(out['value'] * out['ms_per_step'] * 1e-3 - 960000) < 1.0          # the job's samples, counted once per step

@@ -83,7 +83,7 @@ def main():
                 engine.run_nets(nets, x, cond, precision=prec)
             torch.cuda.synchronize()
             engine.EVENT_LOG = None
-            ts = [a.elapsed_time(b) * 1e3 for tag, a, b, _, _ in log if tag == 'persist']
+            ts = [en[1].elapsed_time(en[2]) * 1e3 for en in log if en[0] == 'persist']
             print('persistent launch alone (zero kernel + %d layers): %s us = %.1f us per layer-pair' % (L - 2, ['%.0f' % v for v in ts], min(ts) / (L - 2)))
         print('%s: %.3f ms per stack call (%d nets x %d layers x %d rows) = %.1f us per layer-pair, status %d'
               % ('persistent' if persist else 'per-layer ', ms, G, L, rows, ms * 1e3 / L, engine.persist_status()), flush=True)
