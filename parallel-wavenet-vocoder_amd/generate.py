@@ -167,6 +167,12 @@ def generate(case='default', ckpt=None, debug=False):
         if missing:
             raise KeyError('checkpoint %s does not hold %d of the model\'s %d variables (they would be random-initialised): %s%s'
                            % (ckpt, len(missing), len(store.vars), ', '.join(missing[:6]), ' ...' if len(missing) > 6 else ''))
+        no_shadow = store.ema_missing() if hp.train.use_ema else []
+        if no_shadow:
+            # with use_ema the reference restores EVERY trainable variable of 'iaf_vocoder' from its shadow (generate.py:59-63);
+            # a checkpoint without one fails there, it does not fall back to the raw variable
+            raise KeyError('checkpoint %s has no ExponentialMovingAverage shadow for %d model variable(s) although train.use_ema is '
+                           'set: %s%s' % (ckpt, len(no_shadow), ', '.join(no_shadow[:6]), ' ...' if len(no_shadow) > 6 else ''))
         print('Successfully loaded checkpoint {} ({} variables)'.format(ckpt, n))
     if debug:
         e1.record()
@@ -227,6 +233,8 @@ def _generate_over_ranks(store, batch_size, length, device, logdir, ckpt, debug)
     if ckpt and store.not_restored():
         missing = store.not_restored()
         raise KeyError('checkpoint %s does not hold %d of the model\'s %d variables: %s' % (ckpt, len(missing), len(store.vars), ', '.join(missing[:6])))
+    if ckpt and hp.train.use_ema and store.ema_missing():
+        raise KeyError('checkpoint %s has no ExponentialMovingAverage shadow for: %s' % (ckpt, ', '.join(store.ema_missing()[:6])))
     if rank != 0:
         return None
     pred_wav = pred.cpu().numpy()

@@ -30,7 +30,8 @@ class VariableStore:
         self.seed = seed
         self.vars: Dict[str, torch.Tensor] = {}
         self.version = 0            # bumped on every change; packed-weight caches key on it
-        self.restored = set()       # names set from a checkpoint / dict (what tf.train.Saver.restore covered)
+        self.restored = set()                       # names set from a checkpoint / dict (what tf.train.Saver.restore covered)
+        self.restored_without_shadow = set()        # ... of those, under use_ema, the ones whose shadow the checkpoint lacks
 
     # -- tf.get_variable -------------------------------------------------------------------
     def get_variable(self, name: str, shape: Sequence[int], initializer: Optional[str] = None) -> torch.Tensor:
@@ -79,8 +80,18 @@ class VariableStore:
                 continue
             self.assign(name.split(':')[0], weights[key])
             self.restored.add(name.split(':')[0])
+            if use_ema and key == name:
+                self.restored_without_shadow.add(name.split(':')[0])
+            else:
+                self.restored_without_shadow.discard(name.split(':')[0])
             loaded += 1
         return loaded
+
+    def ema_missing(self, scope: str = 'iaf_vocoder'):
+        """Model variables under `scope` that a use_ema restore took from the RAW variable because the checkpoint has no
+        ``<name>/ExponentialMovingAverage`` for them.  The reference's Saver maps every trainable variable of 'iaf_vocoder'
+        to its shadow name (generate.py:59-63) and fails on a missing key; callers that mirror it treat this list as an error."""
+        return sorted(k for k in self.vars if k in self.restored_without_shadow and k.startswith(scope))
 
     def load_npz(self, path: str, use_ema: bool = False) -> int:
         with np.load(path) as z:

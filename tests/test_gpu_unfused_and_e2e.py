@@ -153,6 +153,13 @@ def test_generate_end_to_end_with_tf_checkpoint(gpu, tmp_path, monkeypatch):
     (logdir / 'checkpoint').write_text('model_checkpoint_path: "model-200"\n')
     with pytest.raises(KeyError, match='layer3/dense'):
         generate('bench/c1')
+    # ... and with train.use_ema (default.yaml:47) a variable whose SHADOW is missing fails too: the reference's Saver is
+    # keyed by the shadow names (generate.py:59-63), it never falls back to the raw variable
+    no_shadow = {k: v for k, v in ck.items() if k != 'iaf_vocoder/iaf0/shifter/dilated_stack/layer2/gate/ExponentialMovingAverage'}
+    T.write_tf_checkpoint(str(logdir / 'model-300'), no_shadow)
+    (logdir / 'checkpoint').write_text('model_checkpoint_path: "model-300"\n')
+    with pytest.raises(KeyError, match='no ExponentialMovingAverage shadow.*layer2/gate'):
+        generate('bench/c1')
 
 
 def test_sampled_noise_differs_between_calls_and_models(gpu):

@@ -174,3 +174,53 @@ def test_ema_preference_and_skipped_entries(tmp_path):
     store2 = VariableStore(device='cpu')
     store2.load_checkpoint(prefix, use_ema=False)
     assert np.array_equal(store2.vars[name].numpy(), t[name])
+
+
+def test_reads_a_bundle_its_writer_never_touched():
+    """tests/golden/tf_bundle_fixture.* was assembled byte by byte by tests/golden/make_tf_bundle_fixture.py from the
+    published LevelDB table / TensorBundle formats -- that script does not import pwv_amd.tf_checkpoint -- so a shared
+    misunderstanding of BundleHeaderProto / BundleEntryProto tags, the restart array, the block trailer or the footer
+    between OUR writer and OUR reader cannot hide here.  (Prefix-compressed keys, an int64 scalar, an EMA shadow.)"""
+    import os
+    from pwv_amd.tf_checkpoint import list_variables, read_tf_checkpoint
+    from pwv_amd.variables import VariableStore
+    prefix = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tf_bundle_fixture')
+    src = open(os.path.join(os.path.dirname(prefix), 'make_tf_bundle_fixture.py')).read()
+    assert 'import pwv_amd' not in src and 'from pwv_amd' not in src and 'tf_checkpoint import' not in src
+    assert list_variables(prefix) == {'global_step': ((), 9), 'iaf_vocoder/cond/dense': ((1, 2, 3), 1),
+                                      'iaf_vocoder/cond/dense/ExponentialMovingAverage': ((1, 2, 3), 1)}
+    got = read_tf_checkpoint(prefix, verify=True)
+    assert got['global_step'].dtype == np.int64 and int(got['global_step']) == 1234
+    np.testing.assert_array_equal(got['iaf_vocoder/cond/dense'], np.arange(6, dtype=np.float32).reshape(1, 2, 3) / 8)
+    np.testing.assert_array_equal(got['iaf_vocoder/cond/dense/ExponentialMovingAverage'], -np.arange(6, dtype=np.float32).reshape(1, 2, 3) / 4)
+    # a flipped payload byte is caught by the tensor's crc, a flipped index byte by the block trailer
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for ext in ('.index', '.data-00000-of-00001'):
+            shutil.copy(prefix + ext, os.path.join(d, 'm' + ext))
+        raw = bytearray(open(os.path.join(d, 'm.data-00000-of-00001'), 'rb').read())
+        raw[9] ^= 1
+        open(os.path.join(d, 'm.data-00000-of-00001'), 'wb').write(bytes(raw))
+        with pytest.raises(ValueError, match='crc32c mismatch'):
+            read_tf_checkpoint(os.path.join(d, 'm'))
+    # EMA preference through the variable store (generate.py:59-63)
+    store = VariableStore(device='cpu')
+    store.load_checkpoint(prefix, use_ema=True)
+    assert float(store.vars['iaf_vocoder/cond/dense'][0, 1, 2]) == -1.25 and store.ema_missing() == []
+    store2 = VariableStore(device='cpu')
+    store2.load_checkpoint(prefix, use_ema=False)
+    assert float(store2.vars['iaf_vocoder/cond/dense'][0, 1, 2]) == 0.625
+
+
+def test_use_ema_restore_reports_variables_without_a_shadow():
+    """generate.py:59-63 maps every trainable variable of 'iaf_vocoder' to its ExponentialMovingAverage name: a checkpoint
+    lacking one fails Saver.restore.  The store records the fallback so that generate() can fail the same way."""
+    from pwv_amd.variables import VariableStore
+    store = VariableStore(device='cpu')
+    w = {'iaf_vocoder/a': np.ones((2,), np.float32), 'iaf_vocoder/a/ExponentialMovingAverage': np.zeros((2,), np.float32),
+         'iaf_vocoder/b': np.ones((3,), np.float32)}
+    store.load_dict(w, use_ema=True)
+    assert store.ema_missing() == ['iaf_vocoder/b'] and float(store.vars['iaf_vocoder/a'][0]) == 0.0
+    store.load_dict({'iaf_vocoder/b/ExponentialMovingAverage': np.full((3,), 2, np.float32)}, use_ema=True)
+    assert store.ema_missing() == []
