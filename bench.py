@@ -378,11 +378,17 @@ def main():
         #          ('persist', ...) ONE persistent launch covering `cnt` layers of `gnets` nets
         pers = [(ref.elapsed_time(en[1]), ref.elapsed_time(en[2]), en[4], en[3]) for en in log if en[0] == 'persist']
         first_runs = sum(en[3] for en in log if en[0] == 'persist' and len(en) > 5 and en[5])      # net-layers that read 4 B instead of 256 B per sample
-        chains = [(ref.elapsed_time(e0), ref.elapsed_time(e1), cnt, gnets) for tag, e0, e1, gnets, cnt in log if tag == 'layer_residual']
+        chains = [(ref.elapsed_time(en[1]), ref.elapsed_time(en[2]), en[4], en[3]) for en in log if en[0] == 'layer_residual']
         if pers:
-            total_ms = sum(e - b for b, e, _, _ in pers)
+            # a forward has a few distinct launches (9- and 29-layer runs); take the MEDIAN duration of each kind over the timed
+            # forwards (the events also span the host's enqueue of the control-word kernel: a late enqueue is not kernel time)
+            kinds = {}
+            for b, e, cnt, gnets in pers:
+                kinds.setdefault((cnt, gnets), []).append(e - b)
+            med = {k: sorted(v)[len(v) // 2] for k, v in kinds.items()}
+            total_ms = sum(med[(cnt, gnets)] for _, _, cnt, gnets in pers)
             timing = {'kind': 'persist', 'launches': len(pers), 'total_ms': total_ms, 'net_layers': sum(cnt * g for _, _, cnt, g in pers),
-                      'launch_ms': [min(e - b for b, e, _, _ in pers), max(e - b for b, e, _, _ in pers)],
+                      'launch_ms': [min(med.values()), max(med.values())],
                       'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3], 'first_net_layers': first_runs}
         elif chains:
             busy = merged_length([(b, e) for b, e, _, _ in chains])
@@ -438,6 +444,10 @@ def main():
             result['dryrun'] = 'control flow only: no kernels ran, value is meaningless (PWV_BENCH_DRYRUN=control)'
         mb, mf = model_algorithmic_work(hp, 2 if args.precision == 'f16' else 4)
         layer_bytes = LAYER_BYTES_PER_SAMPLE // 2 if args.precision == 'f16' else LAYER_BYTES_PER_SAMPLE
+        if hp.model.cond_upsample_method == 'transposed_conv':
+            # per-sample condition: every layer also reads the [rows, C] condition (fp32 tile32 / fp16 hi+lo planes: 4 B per
+            # channel; fp16 mode: 2 B) -- SURVEY.md section 8d, cond_b = C * b
+            layer_bytes += int(hp.model.condition_channels) * (2 if args.precision == 'f16' else 4)
         if timing is not None and timing['kind'] == 'persist':
             # the dominant kernel is the persistent stack kernel: one launch runs `layers` residual layers of both nets of a flow
             # over all timed launches; a run that starts with the net's layer 0 reads 4 B per sample there instead of a 256 B row
@@ -448,12 +458,12 @@ def main():
             roof = {'kernel': 'stack_persist_kernel (persistent dataflow launch: %s residual layers x %d nets per launch, split-fp16 MFMA)'
                               % ('/'.join(str(c) for c in timing['layers_per_launch']), timing['nets_per_launch']),
                     'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS,
-                    'launches_timed': timing['launches'], 'launch_ms_min_max': timing['launch_ms'],
+                    'launches_timed': timing['launches'], 'launch_ms_median_by_kind': timing['launch_ms'],
                     'us_per_layer_pair': timing['total_ms'] * 1e3 / (timing['net_layers'] / timing['nets_per_launch']),
                     'alg_bytes_per_net_layer': rows * layer_bytes, 'alg_flop_per_net_layer': rows * LAYER_FLOP_PER_SAMPLE,
                     'traffic': None,
                     'note': 'achieved = algorithmic bytes (512 B per sample, net and layer) of the layers a launch runs / its duration, '
-                            'HIP events around each persistent launch on its stream (all timed launches pooled)'}
+                            'HIP events around each persistent launch on its stream (median per kind of launch over the timed forwards)'}
             tpath = latest_profile_json('_hbm_traffic.json')
             if args.case == 'bench/c3' and rows == 160000 and tpath:
                 with open(tpath) as f:
@@ -461,13 +471,15 @@ def main():
                 if tj.get('kernel', '').startswith('stack_persist') or 'stack_persist' in tj.get('kernel', ''):
                     roof['traffic'] = tj['traffic_bytes_per_net_layer']
                     roof['traffic_source'] = os.path.relpath(tpath, ROOT)
-                    if 'rocprof_kernel_us' in tj:
-                        roof['rocprof_kernel_us'] = tj['rocprof_kernel_us']
+                    for k in ('rocprof_kernel_us', 'rocprof_us_per_layer_pair'):
+                        if k in tj:
+                            roof[k] = tj[k]
             result['roofline'] = roof
             result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS,
                                        'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)', 'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
         elif timing is not None:
             layer_ms, nets_per_launch = timing['layer_ms'], timing['nets_per_launch']
+            per_sample = 1 if hp.model.cond_upsample_method == 'transposed_conv' else 0
             # scalar / shifter chains on two streams: the measured overlap of the chains' busy intervals (sum / union) says
             # how many launches of this kernel share the chip on average
             concurrent = timing['overlap']
@@ -501,14 +513,14 @@ def main():
                                           'frac': ach_gbs / PEAK_HBM_GBS}
             elif args.precision == 'f16':
                 # fp16 rows: 160 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
-                result['roofline'] = dict(kernel='layer_h16_kernel<0,0> (fused gated-residual layer, fp16 rows, %d nets/launch)' % nets_per_launch,
+                result['roofline'] = dict(kernel='layer_h16_kernel<%d,0> (fused gated-residual layer, fp16 rows%s, %d nets/launch)' % (per_sample, ', per-sample condition' if per_sample else '', nets_per_launch),
                                           bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
                                           frac=ach_gbs / PEAK_HBM_GBS, **common)
                 result['roofline_mfma'] = {'bound': 'mfma', 'achieved': ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                            'frac': ach_tf / PEAK_F16_MFMA_TFLOPS}
             else:
                 # split-fp16 MFMA: 3 x 80 = 240 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
-                result['roofline'] = dict(kernel='layer_f16x3_kernel<0,0,0> (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
+                result['roofline'] = dict(kernel='layer_f16x3_kernel<0,%d,0> (fused gated-residual layer%s, %d nets/launch)' % (per_sample, ', per-sample condition' if per_sample else '', nets_per_launch),
                                           bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
                                           frac=ach_gbs / PEAK_HBM_GBS, **common)
                 result['roofline']['limiter'] = ('two stacked limits, neither of them HBM: (1) issue -- every VALU instruction takes 2-2.7 cycles of matrix-pipe '

@@ -13,13 +13,18 @@ arithmetic lives in librosa 0.5.1 (requirements.txt; not installable here):
 so the mel has exactly 1 + length/hop frames and values in [-1, 1], which is what the network
 was trained on.  File reading, trimming and padding are host-side data preparation; the spectrogram itself
 (STFT -> mel -> dB -> normalisation) also exists as a HIP kernel (`wav_to_mel_device`, csrc/pwv_audio.hip) so that
-generate() on wav input keeps the mel on the device; the numpy functions below are its restatement and its test
-reference.  Parity with librosa is by construction from its documented algorithms (no librosa here to diff against; the
+generate() on wav input keeps the mel on the device.  ROLE OF THE NUMPY FUNCTIONS: `wav2melspec_db` and its helpers are a
+CPU restatement of the reference recipe that serves (a) as the host path for .npy / CPU-side inputs and (b) as the CHECKER
+of the HIP kernel in tests/test_gpu_unfused_and_e2e.py::test_device_mel_frontend_matches_numpy_restatement -- they are test
+reference living in the product package, not an independent oracle; `trim_wav` (librosa.effects.trim) and the resampling in
+`read_wav` have property tests only (tests/test_audio_frontend.py).  Parity with librosa is by construction from its documented algorithms (no librosa here to diff against; the
 STFT is checked against scipy.signal.stft and the filterbank against hand-derived constants in tests/test_audio_frontend.py);
 resampling uses scipy's polyphase filter where librosa used resampy (only matters when the file's
 rate differs from hp.signal.sr).
 """
 from __future__ import annotations
+
+from typing import Optional
 
 import numpy as np
 
@@ -145,9 +150,10 @@ def analysis_window(n_fft: int, win_length: int) -> np.ndarray:
 _device_consts = {}
 
 
-def wav_to_mel_device(wav, normalise: bool = True):
-    """wav [N, L] float32 on the GPU -> normalised dB mel [N, 1 + L/hop, n_mels] on the GPU (pwv_wav_to_mel_db_f32),
-    with the current hparams' signal settings."""
+def wav_to_mel_device(wav, normalise: Optional[bool] = None):
+    """wav [N, L] float32 on the GPU -> (normalised) dB mel [N, 1 + L/hop, n_mels] on the GPU (pwv_wav_to_mel_db_f32),
+    with the current hparams' signal settings.  Like audio.wav2melspec_db (audio.py:350) the dB range is normalised only
+    when BOTH max_db and min_db are set; `normalise` overrides."""
     import torch
     from . import _lib, engine
     s = hp.signal
@@ -161,8 +167,11 @@ def wav_to_mel_device(wav, normalise: bool = True):
                                torch.from_numpy(mel_filterbank(s.sr, s.n_fft, s.n_mels).astype(np.float32)).to(wav.device))
     window, basis = _device_consts[key]
     mel = torch.empty((n, 1 + length // s.hop_length, s.n_mels), dtype=torch.float32, device=wav.device)
+    if normalise is None:
+        normalise = bool(s.get('max_db', None) and s.get('min_db', None))
+    max_db, min_db = (float(s.max_db), float(s.min_db)) if normalise else (1.0, 0.0)      # (unused by the kernel when not normalising)
     _lib.check(_lib.lib().pwv_wav_to_mel_db_f32(wav.data_ptr(), window.data_ptr(), basis.data_ptr(), mel.data_ptr(), n, length, s.n_fft,
-                                                s.hop_length, s.n_mels, 1e-5, 80.0, float(s.max_db), float(s.min_db), int(normalise),
+                                                s.hop_length, s.n_mels, 1e-5, 80.0, max_db, min_db, int(normalise),
                                                 engine._stream()), 'pwv_wav_to_mel_db_f32')
     return mel
 

@@ -702,11 +702,11 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     }
     for (int g = 0; g < a->G; ++g)
         PWV_CHECK_ARG(!any_skip || a->skip[g], "pwv_wavenet_layer_f32: skip must be set for all nets or none");
-    const bool fusable = a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32;
-    PWV_CHECK_ARG(!a->x_first || (fusable && !any_skip), "pwv_wavenet_layer_f32: x_first needs PWV_PREC_F16X3 or PWV_PREC_F32 and no skip accumulation");
-    PWV_CHECK_ARG(!a->head_packed[0] || (fusable && a->out_mode == PWV_OUT_GATED && !any_skip && !a->cond && !a->x_first && a->head_q >= 1 && a->head_q <= kMaxQ),
-                  "pwv_wavenet_layer_f32: a fused head needs PWV_PREC_F16X3 or PWV_PREC_F32, out_mode PWV_OUT_GATED, no skip accumulation, no per-sample "
-                  "condition and head_q in [1,%d]", kMaxQ);
+    const bool half16 = a->precision == PWV_PREC_F16;      // (its fused head has room for the per-sample condition weights)
+    PWV_CHECK_ARG(!a->x_first || !any_skip, "pwv_wavenet_layer_f32: x_first does not support skip accumulation");
+    PWV_CHECK_ARG(!a->head_packed[0] || (a->out_mode == PWV_OUT_GATED && !any_skip && (!a->cond || half16) && !a->x_first && a->head_q >= 1 && a->head_q <= kMaxQ),
+                  "pwv_wavenet_layer_f32: a fused head needs out_mode PWV_OUT_GATED, no skip accumulation, no per-sample condition (PWV_PREC_F16: "
+                  "allowed) and head_q in [1,%d]", kMaxQ);
     lp.head_q = a->head_q;
     lp.x_first = a->x_first;
     lp.x_limit = a->x_limit;
@@ -750,6 +750,7 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
     if (a->precision == PWV_PREC_F16) {
         PWV_CHECK_ARG(!any_skip, "pwv_wavenet_layer_f32: PWV_PREC_F16 does not support skip accumulation");
         // 4-wave workgroups with 40 KB (60 KB with cond) of LDS: several per CU
+        if (lp.packed_head[0]) return launch_layer_h16(lp, cond, gated, g8, s);      // fused head: one 8-wave workgroup per CU
         const int want = per_net * (cond ? 2 : 3);
         return launch_layer_h16(lp, cond, gated, want < nt4 ? want : nt4, s);
     }
@@ -825,8 +826,7 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
     }
     const bool use_skip = a->skip[0] != nullptr;
     // split-fp16 and fp32 paths, plain last layer: the head runs inside the last layer's launch (pwv_layer_args.head_packed)
-    const bool fuse_head = !a->separate_head && (a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32) && !use_skip && !a->cond &&
-                           a->n_layers >= 2;
+    const bool fuse_head = !a->separate_head && !use_skip && (!a->cond || a->precision == PWV_PREC_F16) && a->n_layers >= 2;
     int cur = 0;
     for (int j = 0; j < a->n_layers; ++j) {
         const bool last = j == a->n_layers - 1;

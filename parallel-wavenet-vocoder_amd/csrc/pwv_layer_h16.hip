@@ -68,14 +68,85 @@ constexpr int kH_A2 = kH_A1 + 4 * 8 * 64;      // 2048
 constexpr int kH_AC = kH_A2 + 2 * 4 * 64;      // 2560
 constexpr int kH_END = kH_AC + 4 * 5 * 64;     // 3840 units = 61,440 B (with cond); 40,960 B without
 
+// head (modules.py:145-165) LDS map, in 16-byte units behind the layer's: skip hi [4][4][64] | postprocess1 hi [4][8][64] | floats
+constexpr int kHH_AS = 0;
+constexpr int kHH_A1 = kHH_AS + 4 * 4 * 64;
+constexpr int kHH_END = kHH_A1 + 4 * 8 * 64;     // 3072 units = 49,152 B
+constexpr int kHH_FLOATS = 128 + 128 + 2 * kMaxQ * 64 + 4;   // skip bias, post1 bias, post2 weights, post2 bias
+
+// the head on a lane's gated output o (fp16 fragments oh[4], the B operand of the skip GEMM) -> Q fp32 outputs of row `row`
+__device__ __forceinline__ void head_h16_unit(const f16x8* hl, const float* fl, const f16x8 (&ob)[4], int lane, int h, int Q, bool valid,
+                                              float* out, int row) {
+    const float* bs = fl;
+    const float* b1 = fl + 128;
+    const float* w2 = fl + 256;
+    f32x16 accs[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[it][r] = bs[h * 64 + it * 16 + r];
+    gemm_h<4, 4>(&hl[kHH_AS], lane, accs, [&](int s) -> f16x8 { return ob[s]; });
+    f16x8 sb[8];
+    {
+        float r[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
+        sb[0] = to_h8<0>(r);
+        sb[1] = to_h8<8>(r);
+        sb[2] = to_h8<16>(r);
+        sb[3] = to_h8<24>(r);
+        sb[4] = to_h8<32>(r);
+        sb[5] = to_h8<40>(r);
+        sb[6] = to_h8<48>(r);
+        sb[7] = to_h8<56>(r);
+    }
+    f32x16 acc1[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[it][r] = b1[h * 64 + it * 16 + r];
+    gemm_h<8, 4>(&hl[kHH_A1], lane, acc1, [&](int s) -> f16x8 { return sb[s]; });
+    for (int q = 0; q < Q; ++q) {
+        float part = 0.f;
+        const float* w = &w2[(h * Q + q) * 64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[i], part);
+        part += __shfl_xor(part, 32);
+        part += w2[2 * Q * 64 + q];
+        if (valid && h == 0) out[(size_t)row * Q + q] = part;
+    }
+}
+
+__device__ __forceinline__ void stage_head_h16(f16x8* hl, float* fl, const float* packed, int Q, int wave, int lane, int tid, int waves) {
+    if (waves == 8) {
+        fill_lds_dma<4 * 4 * 64, 8>(reinterpret_cast<float*>(&hl[kHH_AS]), packed + kHAS, wave, lane);
+        fill_lds_dma<4 * 8 * 64, 8>(reinterpret_cast<float*>(&hl[kHH_A1]), packed + kHA1, wave, lane);
+    } else {
+        fill_lds_dma<4 * 4 * 64, 4>(reinterpret_cast<float*>(&hl[kHH_AS]), packed + kHAS, wave, lane);
+        fill_lds_dma<4 * 8 * 64, 4>(reinterpret_cast<float*>(&hl[kHH_A1]), packed + kHA1, wave, lane);
+    }
+    if (tid < 128) {
+        fl[tid] = packed[kHBS + tid];
+        fl[128 + tid] = packed[kHB1 + tid];
+    }
+    for (int i = tid; i < 2 * Q * 64 + 4; i += waves * 64) fl[256 + i] = packed[kHW2 + i];
+}
+
 #ifndef PWV_H16_MINWAVES
 #define PWV_H16_MINWAVES 2
 #endif
-template <bool COND, bool GATED>
-__global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const LayerParams p) {
-    constexpr int WAVES = 4;
+// FIRST: layer 0 of a scalar-input net rebuilds the causal layer's fp16 rows from four scalars per row with the operations of
+// iaf_front_h16_kernel (fp32 fma, then ONE rounding to fp16): no front launch, no [rows, 64] fp16 buffer written and read twice.
+// HEAD: the LAST layer with the head behind it -- the gated output's fp16 fragments are the B operand of the skip GEMM, exactly
+// the bits head_h16_kernel would have read back from HBM.  103 KB of LDS with a per-sample condition: one 8-wave workgroup per CU.
+template <bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
+__global__ __launch_bounds__(HEAD ? 512 : 256, HEAD ? 1 : PWV_H16_MINWAVES) void layer_h16_kernel(const LayerParams p) {
+    static_assert(!HEAD || GATED, "HEAD: the last layer only");
+    constexpr int WAVES = HEAD ? 8 : 4;
     constexpr int kUnits = COND ? kH_END : kH_AC;
-    __shared__ __attribute__((aligned(16))) f16x8 lds[kUnits + 64 / 4 + 1];   // + BD (64 floats) + counter
+    constexpr int kCF = kUnits + 64 / 4 + 1;                        // FIRST: causal filter [2][64] floats = 32 units
+    constexpr int kHD = kCF + (FIRST ? 32 : 0);                     // HEAD: head weights + floats
+    __shared__ __attribute__((aligned(16))) f16x8 lds[kHD + (HEAD ? kHH_END + (kHH_FLOATS + 3) / 4 : 0)];   // + BD (64 floats) + counter
     float* bd_lds = reinterpret_cast<float*>(&lds[kUnits]);
     int* unit_counter = reinterpret_cast<int*>(&lds[kUnits + 16]);
 
@@ -93,6 +164,11 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
     if constexpr (COND) fill_lds_dma<4 * 5 * 64, WAVES>(reinterpret_cast<float*>(&lds[kH_AC]), packed + kLayerBase, wave, lane);
     if (tid < 64) bd_lds[tid] = packed[kBD + tid];
     if (tid == 0) *unit_counter = WAVES;
+    const float* cf = reinterpret_cast<const float*>(&lds[kCF]);
+    if constexpr (FIRST) {
+        if (tid < 128) reinterpret_cast<float*>(&lds[kCF])[tid] = p.cfilt[net][tid];
+    }
+    if constexpr (HEAD) stage_head_h16(&lds[kHD], reinterpret_cast<float*>(&lds[kHD + kHH_END]), p.packed_head[net], p.head_q, wave, lane, tid, WAVES);
     __syncthreads();
 
     const _Float16* xin = reinterpret_cast<const _Float16*>(p.x_in[net]);
@@ -118,12 +194,34 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
         const _Float16* xr = xin + xoff(rc, h, 64);
         const _Float16* xp = xin + xoff(has_prev ? rc - p.dilation : rc, h, 64);
         f16x8 b[8];          // k-steps 0..3 = x[t-d], 4..7 = x[t]: straight from HBM into the B operand
+        if constexpr (FIRST) {
+            // the four scalars the two rows are functions of (zero left of the utterance start), then per k-step the lane's eight
+            // channels 16s + 8(q>>2) + 4h + (q&3): round(x[t-1] w0), fma(x[t], w1, .), one rounding to fp16 (iaf_front_h16_kernel)
+            const float* x1 = p.x_first;
+            const int d = p.dilation;
+            const float x0 = x1[rc], xm1 = t >= 1 ? x1[rc - (t >= 1 ? 1 : 0)] : 0.f;
+            const float xd0 = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f, xd1 = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            b[4 + s] = *reinterpret_cast<const f16x8*>(xr + s * 512);
-            const f16x8 v = *reinterpret_cast<const f16x8*>(xp + s * 512);
-            const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            b[s] = has_prev ? v : zero;
+            for (int s = 0; s < 4; ++s) {
+                float vc[8], vb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = 16 * s + 8 * (q >> 2) + 4 * h + (q & 3);
+                    vc[q] = fmaf(x0, cf[64 + c], xm1 * cf[c]);
+                    vb[q] = fmaf(xd0, cf[64 + c], xd1 * cf[c]);
+                }
+                const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                b[4 + s] = to_h8<0>(vc);
+                b[s] = has_prev ? to_h8<0>(vb) : zero;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                b[4 + s] = *reinterpret_cast<const f16x8*>(xr + s * 512);
+                const f16x8 v = *reinterpret_cast<const f16x8*>(xp + s * 512);
+                const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                b[s] = has_prev ? v : zero;
+            }
         }
         f16x8 cb[5];
         if constexpr (COND) {
@@ -159,7 +257,9 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
         oh[3] = to_h8<24>(o);
 
         const int ooff = (int)((xoff(row, h, 64) - (size_t)u_begin * (32 * 64)) * 2);      // bytes from this workgroup's first unit
-        if constexpr (GATED) {
+        if constexpr (HEAD) {
+            head_h16_unit(&lds[kHD], reinterpret_cast<const float*>(&lds[kHD + kHH_END]), oh, lane, h, p.head_q, valid, p.head_out[net], row);
+        } else if constexpr (GATED) {
             if (valid) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) store_wt(out_rs, ooff + s * 1024, oh[s]);
@@ -187,17 +287,10 @@ __global__ __launch_bounds__(256, PWV_H16_MINWAVES) void layer_h16_kernel(const 
 }
 
 // ---- head: o (fp16, permuted) -> skip -> relu -> post1 -> relu -> post2 (fp32 out) ----------------------
-constexpr int kHH_AS = 0;                        // skip hi [4][4][64]
-constexpr int kHH_A1 = kHH_AS + 4 * 4 * 64;      // post1 hi [4][8][64]
-constexpr int kHH_END = kHH_A1 + 4 * 8 * 64;     // 3072 units = 49,152 B
-constexpr int kHH_FLOATS = 128 + 128 + 2 * kMaxQ * 64 + 4;   // skip bias, post1 bias, post2 weights, post2 bias
 
 __global__ __launch_bounds__(256) void head_h16_kernel(const HeadParams p) {
     __shared__ __attribute__((aligned(16))) f16x8 lds[kHH_END + (kHH_FLOATS + 3) / 4];
     float* fl = reinterpret_cast<float*>(&lds[kHH_END]);
-    float* bs = fl;
-    float* b1 = fl + 128;
-    float* w2 = fl + 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,15 +298,7 @@ __global__ __launch_bounds__(256) void head_h16_kernel(const HeadParams p) {
     const int net = blockIdx.x % p.G;
     const int wg = blockIdx.x / p.G;
     const int nwg = gridDim.x / p.G;
-    const int Q = p.Q;
-    const float* packed = p.packed[net];
-    fill_lds_dma<4 * 4 * 64, 4>(reinterpret_cast<float*>(&lds[kHH_AS]), packed + kHAS, wave, lane);
-    fill_lds_dma<4 * 8 * 64, 4>(reinterpret_cast<float*>(&lds[kHH_A1]), packed + kHA1, wave, lane);
-    if (tid < 128) {
-        bs[tid] = packed[kHBS + tid];
-        b1[tid] = packed[kHB1 + tid];
-    }
-    for (int i = tid; i < 2 * Q * 64 + 4; i += 256) w2[i] = packed[kHW2 + i];
+    stage_head_h16(lds, fl, p.packed[net], p.Q, wave, lane, tid, 4);
     __syncthreads();
     const _Float16* in = reinterpret_cast<const _Float16*>(p.in[net]);
     const int rows = p.N * p.T;
@@ -225,41 +310,7 @@ __global__ __launch_bounds__(256) void head_h16_kernel(const HeadParams p) {
         f16x8 ob[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) ob[s] = *reinterpret_cast<const f16x8*>(in + xoff(rc, h, 64) + s * 512);
-        f32x16 accs[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accs[it][r] = bs[h * 64 + it * 16 + r];
-        gemm_h<4, 4>(&lds[kHH_AS], lane, accs, [&](int s) -> f16x8 { return ob[s]; });
-        f16x8 sb[8];
-        {
-            float r[64];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
-            sb[0] = to_h8<0>(r);
-            sb[1] = to_h8<8>(r);
-            sb[2] = to_h8<16>(r);
-            sb[3] = to_h8<24>(r);
-            sb[4] = to_h8<32>(r);
-            sb[5] = to_h8<40>(r);
-            sb[6] = to_h8<48>(r);
-            sb[7] = to_h8<56>(r);
-        }
-        f32x16 acc1[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[it][r] = b1[h * 64 + it * 16 + r];
-        gemm_h<8, 4>(&lds[kHH_A1], lane, acc1, [&](int s) -> f16x8 { return sb[s]; });
-        for (int q = 0; q < Q; ++q) {
-            float part = 0.f;
-            const float* w = &w2[(h * Q + q) * 64];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), w[i], part);
-            part += __shfl_xor(part, 32);
-            part += w2[2 * Q * 64 + q];
-            if (valid && h == 0) p.out[net][(size_t)row * Q + q] = part;
-        }
+        head_h16_unit(lds, fl, ob, lane, h, p.Q, valid, p.out[net], row);
     }
 }
 
@@ -341,14 +392,27 @@ __global__ void cond_to_h16_kernel(const float* __restrict__ cond, _Float16* __r
     }
 }
 
+template <bool COND, bool GATED, bool FIRST, bool HEAD>
+static void launch_h16(const LayerParams& lp, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((layer_h16_kernel<COND, GATED, FIRST, HEAD>), dim3(grid), dim3(HEAD ? 512 : 256), 0, s, lp);
+}
+
 int launch_layer_h16(const LayerParams& lp, bool cond, bool gated, int per_net, hipStream_t s) {
     const int grid = per_net * lp.G;
-    if (cond) {
-        if (gated) hipLaunchKernelGGL((layer_h16_kernel<true, true>), dim3(grid), dim3(256), 0, s, lp);
-        else hipLaunchKernelGGL((layer_h16_kernel<true, false>), dim3(grid), dim3(256), 0, s, lp);
+    const bool first = lp.x_first != nullptr, head = lp.packed_head[0] != nullptr;
+    if (head && (!gated || first)) return set_error(PWV_EINVAL, "fp16 fused head: the last layer only (out_mode PWV_OUT_GATED, not layer 0)");
+    if (head) {
+        if (cond) launch_h16<true, true, false, true>(lp, grid, s);
+        else launch_h16<false, true, false, true>(lp, grid, s);
+    } else if (first) {
+        if (cond) { if (gated) launch_h16<true, true, true, false>(lp, grid, s); else launch_h16<true, false, true, false>(lp, grid, s); }
+        else { if (gated) launch_h16<false, true, true, false>(lp, grid, s); else launch_h16<false, false, true, false>(lp, grid, s); }
+    } else if (cond) {
+        if (gated) launch_h16<true, true, false, false>(lp, grid, s);
+        else launch_h16<true, false, false, false>(lp, grid, s);
     } else {
-        if (gated) hipLaunchKernelGGL((layer_h16_kernel<false, true>), dim3(grid), dim3(256), 0, s, lp);
-        else hipLaunchKernelGGL((layer_h16_kernel<false, false>), dim3(grid), dim3(256), 0, s, lp);
+        if (gated) launch_h16<false, true, false, false>(lp, grid, s);
+        else launch_h16<false, false, false, false>(lp, grid, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "fp16 layer kernel launch failed: %s", hipGetErrorString(e));

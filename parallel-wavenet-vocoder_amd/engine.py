@@ -434,8 +434,11 @@ class NetPlan:
         w_max = max(float((st[:, [0, 4]].max()) * kf), float(st[:, [1, 5]].max() * kg), float(st[:, 2:4].max()), post1_max)
         res_bound = float(st[:L - 1, 6].sum())
         skip_bound = float(st[:, 7].sum() if use_skip else st[L - 1, 7])
-        self.f16x3_ok = w_max < F16_LIMIT and skip_bound < F16_LIMIT and res_bound < F16_LIMIT
-        self.x_limit = (F16_LIMIT - res_bound) / c_causal if c_causal > 0 else 3.0e38
+        # normalize='bn': the causal layer is followed by a folded batch norm, h = a0 * conv(x) + c0 -- the shift is part of |h|
+        c0_max = float(self.causal_bias.abs().max()) if self.causal_bias is not None else 0.0
+        budget = F16_LIMIT - res_bound - c0_max
+        self.f16x3_ok = w_max < F16_LIMIT and skip_bound < F16_LIMIT and res_bound < F16_LIMIT and budget > 0
+        self.x_limit = budget / c_causal if c_causal > 0 else 3.0e38
 
 
 _plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
@@ -796,9 +799,9 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # ---- frame-rate projection P (or bias-only row) -------------------------------------------
     main = torch.cuda.current_stream()
     use_skip = bool(net0.use_skip_connection)
-    # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
-    # (pwv_layer_args.x_first), so the [rows, 64] front buffer is neither written nor read
-    first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32) and qin == 1 and net0.filter_width == 2
+    # layer 0 rebuilds the causal layer's output from the scalar input itself (pwv_layer_args.x_first), so the [rows, 64]
+    # front buffer is neither written nor read
+    first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32, _lib.PREC_F16) and qin == 1 and net0.filter_width == 2
                    and net0.residual_channels == 64 and not net0.use_skip_connection and plans[0].causal_bias is None)
     persist = ((prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
                and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1))
