@@ -56,6 +56,10 @@ def main():
     print('loop start %.1f .. %.1f us, loop end %.1f .. %.1f us (chip-wide 100 MHz clock)' % (st.min(), st.max(), en.min(), en.max()))
     clk = tot / ((t[:, 13] - t[:, 14]) / 100.0) / 1e3
     print('shader clock during the loop (s_memtime cycles / s_memrealtime): mean %.3f GHz (min %.3f, max %.3f)' % (clk.mean(), clk.min(), clk.max()))
+    # workgroups of one XCD take consecutive ranges (16 per XCD and net at 256 CUs): is the spread systematic per XCD?
+    for g in sorted(set(int(r[11]) // 16 for r in t)):
+        m = np.array([int(r[11]) // 16 == g for r in t])
+        print('  ranges %3d..%3d (one XCD): waves finish at %.1f .. %.1f us, mean loop %.0f cycles' % (16 * g, 16 * g + 15, en[m].min(), en[m].max(), tot[m].mean()))
     per_wg = {}
     for r in t:
         per_wg.setdefault((int(r[10]), int(r[11])), []).append(r[0])
@@ -64,5 +68,42 @@ def main():
           % (len(wg_tot), wg_tot.mean(), wg_tot.min(), wg_tot.max(), 100 * (wg_tot.max() - wg_tot.min()) / wg_tot.mean()))
 
 
+def xcd_series(reps=8):
+    """Per-XCD finish times of `reps` consecutive launches in one process: is the clock pattern over the XCDs stable?"""
+    rows, L, G = 160000, 10, 2
+    dev = torch.device('cuda', 0)
+    d10 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+    store = VariableStore(device=dev, seed=3)
+    kw = dict(batch_size=1, dilations=d10[:L], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
+              quantization_channels=1, use_biases=True, condition_channels=80, use_skip_connection=False, is_training=False, store=store)
+    nets = [WaveNet(name='n%d' % g, **kw) for g in range(G)]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, rows, 1), generator=g).to(dev)
+    frames = torch.rand((1, rows // 80 + 1, 80), generator=g).to(dev)
+    cond = engine.RepeatedCondition(frames, 80, 40, rows)
+    trace = torch.zeros((2 * 256 * 8, 16), dtype=torch.int64, device=dev)
+    os.environ['PWV_PTRACE_PTR'] = str(trace.data_ptr())
+    engine.PERSIST = True
+    for _ in range(20):
+        engine.run_nets(nets, x, cond)
+    for k in range(reps):
+        torch.cuda.synchronize()
+        trace.zero_()
+        engine.run_nets(nets, x, cond)
+        if k % 2:
+            for _ in range(3):
+                engine.run_nets(nets, x, cond)      # (every other sample a few launches later)
+        torch.cuda.synchronize()
+        t = trace.cpu().numpy().astype(np.float64)
+        t = t[t[:, 5] > 0]
+        t0 = t[:, 14].min()
+        en = (t[:, 13] - t0) / 100.0
+        fin = [en[(t[:, 11] // 16) == x_].max() for x_ in range(8)]
+        print('launch %d: last finish per XCD (us): %s  | spread %.1f us' % (k, ' '.join('%6.1f' % v for v in fin), max(fin) - min(fin)))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'xcd':
+        xcd_series()
+    else:
+        main()
