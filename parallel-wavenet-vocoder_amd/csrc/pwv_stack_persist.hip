@@ -27,7 +27,7 @@
 //    that slot with layer j+2 by LDS-DMA and announces it at its next drain.  The 2 KB that buys the control state come
 //    from the LAST 1 KB fragment of each layer's dense matrix, which every unit reads from global memory (one 16-byte load
 //    per lane, an L1 / L2 hit) instead.
-//  * Every spin is bounded and reports through a sticky status word in pinned host memory; the host then reruns on the
+//  * Every wait is bounded (20 ms, or until any wave of the launch has given up) and reports through a sticky status word in pinned host memory; the host then reruns on the
 //    per-layer path.  All workgroups must be resident (grid <= CUs, one workgroup per CU by its LDS size).
 // Results are bit-identical to the per-layer launches (same per-unit arithmetic): tests/test_gpu_persist.py.
 #include "pwv_f16x3.h"
@@ -53,7 +53,7 @@ constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 864 units per work
 constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
 constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
 constexpr int kMaxPLayers = 32;
-constexpr int kSpinLimit = 1 << 16;            // polls before a wave gives up (tens of ms)
+constexpr long long kWaitTicks = 2000000;      // a wave gives up after 20 ms of the chip-wide 100 MHz clock (normal waits: microseconds)
 constexpr int kProgStride = 32;                // ints between two workgroups' progress words (own 128-byte lines)
 constexpr int kMaxReachWgs = 60;               // neighbours polled by one wave instruction
 
@@ -63,6 +63,7 @@ struct PersistParams {
     const float* packed[PWV_MAX_NETS];     // packed layers of this launch, `packed_stride` floats apart
     const float* proj[PWV_MAX_NETS];       // P rows; this launch's first layer at column 0, layer j at 128 j
     int* prog;                             // [G][nwg] progress words, kProgStride ints apart, zeroed per launch
+    int* abort;                            // one word behind them: != 0 once any wave of the launch has given up
     int* status;                           // pinned host word: != 0 after a give-up
     long long packed_stride;
     int proj_row_stride;
@@ -345,10 +346,15 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         if (lv != j) layer_vectors(j);
         const int addr = dep_addr(j, u);
         bool ok = false;
-        for (int k = 0; k < kSpinLimit && !ok; ++k) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; !ok; ++k) {
             const unsigned bad = eval(addr) & mask;
             if (!bad) { ok = true; break; }
-            if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1])) break;      // (readfirstlane: the loop must stay wave-uniform)
+            // somebody has given up (this workgroup: LDS word; any workgroup of the launch: the word behind the progress words,
+            // looked at every 64th poll), or this wait has lasted 20 ms: give up too.  (readfirstlane: the loop stays wave-uniform)
+            if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1])) break;
+            if ((k & 63) == 63 && (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
+                                   __builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks)) break;
             if ((bad & 0x6u) && __ballot(addr == kSeenLB && (lane == 1 || lane == 2))) poll_side(0, j);
             if ((bad & 0x30u) && __ballot(addr == kSeenRB && (lane == 4 || lane == 5))) poll_side(1, j - 1);
             __builtin_amdgcn_s_sleep(4);
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         // (every lane stores the same words: a lane-0 branch here makes the compiler treat `dead`, and with it the whole
         // task loop, as divergent -- scalar bookkeeping in VGPRs, a waterfall loop around every buffer access)
         __hip_atomic_store(p.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *(__attribute__((address_space(3))) volatile int*)&ctl[1] = 1;
         dead = true;
     };
@@ -719,7 +726,7 @@ size_t pwv_persist_workspace_bytes(const pwv_persist_args* a) {
     const int cus = device_cus();
     if (!a) { set_error(PWV_EINVAL, "pwv_persist_workspace_bytes: NULL argument"); return 0; }
     if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl) != PWV_OK) return 0;
-    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);
+    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);      // progress words + the abort word
 }
 
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream) {
@@ -736,6 +743,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     PWV_CHECK_ARG(a->workspace_bytes >= pwv_persist_workspace_bytes(a), "pwv_wavenet_stack_persist_f32: workspace too small");
     PWV_CHECK_ARG(((uintptr_t)a->workspace & 255) == 0, "pwv_wavenet_stack_persist_f32: workspace must be 256-byte aligned");
     p.prog = (int*)a->workspace;
+    p.abort = p.prog + (size_t)a->G * pl.nwg * kProgStride;
     for (int g = 0; g < a->G; ++g) {
         PWV_CHECK_ARG(a->x_ring[g] && a->packed_layers[g] && a->proj[g], "pwv_wavenet_stack_persist_f32: NULL buffer for net %d", g);
         p.ring[g] = a->x_ring[g];
@@ -780,7 +788,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }
 #endif
     hipStream_t s = (hipStream_t)stream;
-    const size_t n16 = align256((size_t)a->G * pl.nwg * kProgStride * 4) / 16;
+    const size_t n16 = align256((size_t)a->G * pl.nwg * kProgStride * 4 + 16) / 16;
     hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
     if (a->precision == PWV_PREC_F32)
         hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
