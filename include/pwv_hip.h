@@ -387,7 +387,7 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
  *   Results are bit-identical to n_layers calls of pwv_wavenet_layer_f32.
  * Every workgroup owns the same contiguous rows in every layer and walks layer after layer over them; what it needs of
  * its neighbours' rows (the x[t-d] look-back) is handed over through per-workgroup progress words in `workspace`;
- * csrc/pwv_stack_persist.hip has the protocol.  The call enqueues a kernel that zeroes the control words and one kernel
+ * csrc/pwv_stack_persist.hip has the protocol.  The call enqueues (unless `workspace_clean`) a kernel that zeroes the control words and one kernel
  * (grid <= one workgroup per CU; max_workgroups > 0 limits it further, e.g. to share the chip with another stream).
  *   pwv_persist_workspace_bytes   size of `workspace` (device memory, 256-byte aligned, contents don't care) for the shape in
  *                                 `args` (G, N, T, n_layers, dilations, max_workgroups, min_units_per_workgroup are read);
@@ -413,6 +413,8 @@ typedef struct pwv_persist_args {
     int cond_hop, cond_offset, cond_frames;
     void* workspace;
     size_t workspace_bytes;
+    int workspace_clean;                          /* != 0: `workspace` is all zero on entry (fresh, or last used by this entry point, which
+                                                   * zeroes it again before it returns the chip): no zeroing kernel is enqueued */
     int precision;                                /* PWV_PREC_F16X3 or PWV_PREC_F32 (packed_layers packed accordingly) */
     int max_workgroups;                           /* 0 = one per CU */
     int min_units_per_workgroup;                  /* short inputs: use fewer workgroups rather than ranges below this (0 = 4) */

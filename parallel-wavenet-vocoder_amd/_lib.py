@@ -139,6 +139,7 @@ class PersistArgs(Structure):
         ('cond_hop', c_int), ('cond_offset', c_int), ('cond_frames', c_int),
         ('workspace', c_void_p),
         ('workspace_bytes', c_size_t),
+        ('workspace_clean', c_int),
         ('precision', c_int),
         ('max_workgroups', c_int),
         ('min_units_per_workgroup', c_int),

@@ -27,6 +27,8 @@
 //    that slot with layer j+2 by LDS-DMA and announces it at its next drain.  The 2 KB that buys the control state come
 //    from the LAST 1 KB fragment of each layer's dense matrix, which every unit reads from global memory (one 16-byte load
 //    per lane, an L1 / L2 hit) instead.
+//  * The launch leaves its workspace as it found it (zeros): the last workgroup to finish cleans up, so a caller that keeps the
+//    workspace needs no zeroing kernel in front of the next launch (pwv_persist_args.workspace_clean).
 //  * Every wait is bounded (20 ms, or until any wave of the launch has given up) and reports through a sticky status word in pinned host memory; the host then reruns on the
 //    per-layer path.  All workgroups must be resident (grid <= CUs, one workgroup per CU by its LDS size).
 // Results are bit-identical to the per-layer launches (same per-unit arithmetic): tests/test_gpu_persist.py.
@@ -64,6 +66,8 @@ struct PersistParams {
     const float* proj[PWV_MAX_NETS];       // P rows; this launch's first layer at column 0, layer j at 128 j
     int* prog;                             // [G][nwg] progress words, kProgStride ints apart, zeroed per launch
     int* abort;                            // one word behind them: != 0 once any wave of the launch has given up
+    int* exited;                           // ... and one more: workgroups that have finished; the last one zeroes all of these words
+    int active_wgs;                        // workgroups that own units (the others return at once)
     int* status;                           // pinned host word: != 0 after a give-up
     long long packed_stride;
     int proj_row_stride;
@@ -650,6 +654,25 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         leave_layers(L);
         if (dma_pending >= 0) flush_owed();
     }
+    // The launch cleans up after itself: the LAST workgroup to finish zeroes every word a later launch polls (progress, abort,
+    // this counter), so a launch that is handed this workspace again needs no zeroing kernel in front of it.  A wave counts
+    // itself out only when its own global stores are complete (vmcnt(0)): no progress word can land after the zeroing.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(old) == 7) {
+            int done = 0;
+            if (lane == 0) done = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(done) == p.active_wgs - 1) {
+                for (int k = lane; k < p.G * p.nwg; k += 64) __hip_atomic_store(p.prog + (size_t)k * kProgStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    __hip_atomic_store(p.abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
 #ifdef PWV_PTRACE
     if (p.trace && lane == 0) {
         pt_acc[8] = __builtin_amdgcn_s_memtime();
@@ -661,8 +684,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
 #endif
 }
 
-// every polled word starts at zero on EVERY call.  A kernel, not hipMemsetAsync: under stream capture the memset node of a
-// torch-captured graph did not reset the words on replay (tests/test_gpu_persist.py::test_whole_model_persistent_eager_and_graph_replay)
+// every polled word starts at zero on EVERY call: either the caller says the workspace is clean (fresh zeros, or left by an
+// earlier launch, which cleans up after itself) or this kernel runs first.  A kernel, not hipMemsetAsync: under stream capture the
+// memset node of a torch-captured graph did not reset the words on replay (tests/test_gpu_persist.py::test_whole_model_persistent_eager_and_graph_replay)
 __global__ void persist_zero_kernel(int4* p, size_t n16) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n16) p[i] = int4{0, 0, 0, 0};
@@ -726,7 +750,7 @@ size_t pwv_persist_workspace_bytes(const pwv_persist_args* a) {
     const int cus = device_cus();
     if (!a) { set_error(PWV_EINVAL, "pwv_persist_workspace_bytes: NULL argument"); return 0; }
     if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl) != PWV_OK) return 0;
-    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);      // progress words + the abort word
+    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);      // progress words + the abort word + the exit counter
 }
 
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream) {
@@ -744,6 +768,8 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     PWV_CHECK_ARG(((uintptr_t)a->workspace & 255) == 0, "pwv_wavenet_stack_persist_f32: workspace must be 256-byte aligned");
     p.prog = (int*)a->workspace;
     p.abort = p.prog + (size_t)a->G * pl.nwg * kProgStride;
+    p.exited = p.abort + 1;
+    p.active_wgs = a->G * (pl.last_wg + 1);
     for (int g = 0; g < a->G; ++g) {
         PWV_CHECK_ARG(a->x_ring[g] && a->packed_layers[g] && a->proj[g], "pwv_wavenet_stack_persist_f32: NULL buffer for net %d", g);
         p.ring[g] = a->x_ring[g];
@@ -789,7 +815,8 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
 #endif
     hipStream_t s = (hipStream_t)stream;
     const size_t n16 = align256((size_t)a->G * pl.nwg * kProgStride * 4 + 16) / 16;
-    hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
+    if (!a->workspace_clean)
+        hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
     if (a->precision == PWV_PREC_F32)
         hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
     else

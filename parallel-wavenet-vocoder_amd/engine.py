@@ -72,6 +72,7 @@ CHAIN_FLOWS = os.environ.get('PWV_CHAIN_FLOWS', '0') != '0'
 CHAIN_SKEW_US = int(os.environ.get('PWV_CHAIN_SKEW_US', '0'))      # chain 1 leaves every flow boundary this much behind chain 0
 CHAIN_FORWARDS = 0        # forwards that took run_flow_chain (tests / tools look at it)
 _persist_status_addr = None
+_persist_ws = {}          # (device, stream) -> zeroed workspace of the persistent launches on that stream
 _sync_status_addr = None
 _side_streams = {}
 
@@ -524,8 +525,12 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         nbytes = lib.pwv_persist_workspace_bytes(ctypes.byref(pa))
         if nbytes == 0:
             raise _lib.PwvError('pwv_persist_workspace_bytes: %s' % lib.pwv_last_error().decode())
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=bufs[0][0].device)
-        pa.workspace, pa.workspace_bytes = ws.data_ptr(), nbytes
+        # one zero-initialised workspace per (device, stream), kept: a launch leaves it clean, so none needs a zeroing kernel
+        wkey = (bufs[0][0].device, torch.cuda.current_stream().cuda_stream)
+        ws = _persist_ws.get(wkey)
+        if ws is None or ws.numel() < nbytes:
+            ws = _persist_ws[wkey] = torch.zeros((max(nbytes, 1 << 16),), dtype=torch.uint8, device=bufs[0][0].device)
+        pa.workspace, pa.workspace_bytes, pa.workspace_clean = ws.data_ptr(), nbytes, 1
         ev = None
         if EVENT_LOG is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -42,7 +42,11 @@ class GraphedVocoder(object):
 
     def _capture(self):
         # warm up on a side stream (plans packed, side streams created, allocator primed), as stream capture requires
-        side = torch.cuda.Stream(device=self.device)
+        # (one stream for warm-up AND capture: what the warm-up forwards set up per stream -- the persistent launches' zeroed
+        # workspace, engine._persist_ws -- is then found again by the captured forward instead of being allocated inside the graph)
+        if getattr(self, '_stream', None) is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        side = self._stream
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(self._warmup):
@@ -51,7 +55,7 @@ class GraphedVocoder(object):
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: only this thread's calls are policed during capture (an RCCL watchdog thread of a multi-rank
         # job may touch the runtime meanwhile); everything captured here is enqueued from this thread
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
             self.out = self.model(None, self.mel, is_training=False, z=self.z)
         self._version = self.store.version
 
