@@ -222,7 +222,21 @@ def _generate_over_ranks(store, batch_size, length, device, logdir, ckpt, debug)
     def make_model(n, window):
         m = IAFVocoder(batch_size=n, length=window, store=store)
         used.append(m)
-        return lambda mel, z: m(None, mel, is_training=False, z=z)
+
+        def run(mel, z):
+            # checked before the result is gathered: a persistent launch that gave up (only with several processes on one GPU)
+            # has switched the engine to the per-layer launches; same arithmetic, rerun this rank's share
+            for attempt in (0, 1):
+                try:
+                    y = m(None, mel, is_training=False, z=z)
+                    torch.cuda.synchronize()
+                    engine.raise_if_persist_failed()
+                    return y
+                except PwvPersistError as e:
+                    if attempt:
+                        raise
+                    print('%s\nre-running the forward with per-layer launches' % e)
+        return run
 
     def noise_window(n, first_sample, window, first_item):
         return engine.logistic_noise_window(n, length, first_sample, window, device, seed, first_item)
