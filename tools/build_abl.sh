@@ -11,7 +11,7 @@ cp -r "$root/parallel-wavenet-vocoder_amd/csrc" "$tmp/csrc"
 (cd "$tmp" && patch -s -p2 -d . < "$root/tools/probes/perturb.patch")
 mkdir -p "$root/tools/abl_so"
 for v in "$@"; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DPWV_$v -I"$root/include" -I"$tmp/csrc" \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950:xnack- --offload-arch=gfx950:xnack+ -O3 -std=c++17 -shared -fPIC -DPWV_$v -I"$root/include" -I"$tmp/csrc" \
         -o "$root/tools/abl_so/libpwv_$v.so" "$tmp"/csrc/*.hip
     echo "built tools/abl_so/libpwv_$v.so"
 done
