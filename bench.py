@@ -315,18 +315,43 @@ def main():
     def timed_verified(precision, warmup, steps):
         """make_step + timed + the give-up / range check of what was timed.  A persistent launch that gave up (its workgroups
         were not all resident: another process on this GPU, e.g. the two-ranks-on-one-GPU test hook) has switched the engine to
-        the per-layer launches -- never lose the measurement to it: rebuild the step and time again."""
+        the per-layer launches -- never lose the measurement to it: rebuild the step and time again.  With several ranks the
+        decision is taken TOGETHER (one MAX all-reduce), and a give-up never leaves the timed loop early, so that the ranks'
+        barriers stay paired."""
         for attempt in (0, 1):
+            failed = []
             try:
                 made = make_step(precision)
-                elapsed_, out_ = timed(made[0], warmup, steps)
-                if not control:
-                    model0.verify()      # range guard of the split-fp16 arithmetic / give-up word of the persistent launch
-                return made, elapsed_, out_
             except _lib.PwvPersistError as e:
-                if attempt:
-                    raise
-                sys.stderr.write('%s\nre-timing with per-layer launches\n' % e)
+                failed.append(e)
+                made = make_step(precision)          # (the engine is on the per-layer path now)
+            last = [None]
+
+            def guarded():
+                try:
+                    last[0] = made[0]()
+                except _lib.PwvPersistError as e:
+                    failed.append(e)
+                return last[0]
+
+            elapsed_, out_ = timed(guarded, warmup, steps)
+            if not control:
+                try:
+                    model0.verify()      # range guard of the split-fp16 arithmetic / give-up word of the persistent launch
+                except _lib.PwvPersistError as e:
+                    failed.append(e)
+            again = 1 if failed else 0
+            if dist is not None:
+                t = torch.tensor([again], dtype=torch.int32, device='cpu' if dryrun else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                again = int(t.item())
+            if not again:
+                return made, elapsed_, out_
+            if not control:
+                engine.PERSIST = False
+            if attempt:
+                raise failed[0] if failed else _lib.PwvPersistError('a persistent launch gave up on another rank, twice')
+            sys.stderr.write('%s\nre-timing with per-layer launches\n' % (failed[0] if failed else 'a persistent launch gave up on another rank'))
 
     def checked_forward(call):
         """one untimed forward, rerun once if a persistent launch (its own or an earlier one) gave up"""
