@@ -228,6 +228,11 @@ typedef struct pwv_layer_args {
      * traffic per sample for this layer and no front launch.  x_first is [N*T] float32 (the flow's input). */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];   /* [2,1,64] each */
+    /* optional, PWV_PREC_F16X3 with x_first: pwv_pack_first_fold_f16x3's output per net (all nets or none).  Layer 0's
+     * filter|gate convolution then runs on the four scalars x[t-d-1], x[t-d], x[t-1], x[t] themselves -- one MFMA k-step
+     * instead of eight: the same function (h[t] is linear in x[t-1], x[t]), rounded differently: within the path's
+     * tolerance of the unfolded form, not bit-identical to it.  pwv_persist_args.first_fold does exactly the same. */
+    const float* first_fold[PWV_MAX_NETS];
     /* The LAST layer with the post-processing head fused behind it (PWV_PREC_F16X3 / PWV_PREC_F32, out_mode PWV_OUT_GATED, no skip
      * accumulation, no per-sample condition): when head_packed[g] != NULL the gated output stays in registers and
      * feeds pwv_wavenet_head_f32's arithmetic directly; head_out[g] receives [N,T,head_q]; x_out is not written. */
@@ -253,6 +258,12 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* args, pwv_stream_t stream);
 #define PWV_HEAD_IN_SKIPSUM 1
 
 size_t pwv_head_packed_floats(int Q);
+/* Layer 0 of a scalar-input net (W = 2 causal filter [2,1,64] in front of a [2,64,64] filter / gate pair, modules.py:174-183 and
+ * :216-222) folded onto its four input scalars: 2048 floats (8 KB) of split-fp16 A fragments for pwv_persist_args.first_fold.
+ * The fold is accumulated in fp64. */
+#define PWV_FIRST_FOLD_FLOATS 2048
+int pwv_pack_first_fold_f16x3(const float* causal_filter, const float* filter, const float* gate, float* folded, pwv_stream_t stream);
+
 /* skip [1,64,128], skip_bias [128]/NULL, post1 [1,128,128], post1_bias [128]/NULL,
  * post2 [1,128,Q], post2_bias [Q]/NULL */
 int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* post1,
@@ -319,6 +330,7 @@ typedef struct pwv_stack_args {
     int* range_flag;
     const float* x_first_chain1;                  /* two-stream mode: the second chain reads its own copy of the flow input
                                                    * (pwv_iaf_affine_sync_f32); NULL = both nets read x_first */
+    const float* first_fold[PWV_MAX_NETS];        /* optional, forwarded to layer 0 (pwv_layer_args.first_fold) */
 } pwv_stack_args;
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);
@@ -424,6 +436,11 @@ typedef struct pwv_persist_args {
     const float* causal_filter[PWV_MAX_NETS];
     float x_limit;                                /* range guard on x_first (pwv_layer_args.x_limit / range_flag) */
     int* range_flag;
+    /* optional, with x_first and PWV_PREC_F16X3: pwv_pack_first_fold_f16x3's output per net (all nets or none).  Layer 0's
+     * filter|gate GEMM then runs on the four scalars x[t-d-1], x[t-d], x[t-1], x[t] themselves (one MFMA k-step instead of
+     * eight): the same function (h[t] is linear in x[t-1], x[t]), rounded differently -- within the path's tolerance of the
+     * unfolded form, not bit-identical to it */
+    const float* first_fold[PWV_MAX_NETS];
 } pwv_persist_args;
 
 size_t pwv_persist_workspace_bytes(const pwv_persist_args* args);

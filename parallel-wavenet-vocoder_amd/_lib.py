@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so') 
 CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip',
                                                     'pwv_stack_persist.hip', 'pwv_norm.hip', 'pwv_audio.hip')]
 
+FIRST_FOLD_FLOATS = 2048      # PWV_FIRST_FOLD_FLOATS
 PWV_MAX_NETS = 2
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
 OUT_RESIDUAL, OUT_GATED = 0, 1
@@ -30,7 +31,7 @@ EXPORTED_SYMBOLS = (
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
-    'pwv_linear_split_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_range_check_f32', 'pwv_range_stats_f32',
+    'pwv_linear_split_f32', 'pwv_pack_first_fold_f16x3', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_range_check_f32', 'pwv_range_stats_f32',
     'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32', 'pwv_iaf_affine_sync_f32', 'pwv_sync_status',
     'pwv_wav_to_mel_db_f32', 'pwv_pack_proj_f32', 'pwv_instance_norm_workspace_bytes', 'pwv_instance_norm_f32', 'pwv_channel_affine_f32', 'pwv_add_f32', 'pwv_gate_f32',
 )
@@ -70,6 +71,7 @@ class LayerArgs(Structure):
         ('max_workgroups', c_int),
         ('x_first', c_void_p),
         ('causal_filter', c_void_p * PWV_MAX_NETS),
+        ('first_fold', c_void_p * PWV_MAX_NETS),
         ('head_packed', c_void_p * PWV_MAX_NETS),
         ('head_out', c_void_p * PWV_MAX_NETS),
         ('head_q', c_int),
@@ -120,6 +122,7 @@ class StackArgs(Structure):
         ('x_limit', ctypes.c_float),
         ('range_flag', c_void_p),
         ('x_first_chain1', c_void_p),
+        ('first_fold', c_void_p * PWV_MAX_NETS),
     ]
 
 
@@ -147,6 +150,7 @@ class PersistArgs(Structure):
         ('causal_filter', c_void_p * PWV_MAX_NETS),
         ('x_limit', ctypes.c_float),
         ('range_flag', c_void_p),
+        ('first_fold', c_void_p * PWV_MAX_NETS),
     ]
 
 
@@ -204,6 +208,7 @@ def _declare(lib):
     lib.pwv_head_packed_floats.restype = c_size_t
     lib.pwv_head_packed_floats.argtypes = [c_int]
     lib.pwv_pack_head_f32.argtypes = [f32p] * 6 + [c_int, c_int, f32p, c_void_p]
+    lib.pwv_pack_first_fold_f16x3.argtypes = [f32p, f32p, f32p, f32p, c_void_p]
     lib.pwv_wavenet_head_f32.argtypes = [POINTER(HeadArgs), c_void_p]
     lib.pwv_wavenet_stack_f32.argtypes = [POINTER(StackArgs), POINTER(c_void_p)]
     lib.pwv_pack_proj_f32.argtypes = [f32p, f32p, f32p, f32p, c_int, c_int, c_int, f32p, f32p, c_void_p]

@@ -655,6 +655,11 @@ int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dens
     return PWV_OK;
 }
 
+int pwv_pack_first_fold_f16x3(const float* causal_filter, const float* filter, const float* gate, float* folded, pwv_stream_t stream) {
+    PWV_CHECK_ARG(causal_filter && filter && gate && folded, "pwv_pack_first_fold_f16x3: NULL pointer");
+    return launch_pack_first_fold_f16x3(causal_filter, filter, gate, folded, (hipStream_t)stream);
+}
+
 int pwv_pack_head_f32(const float* skip, const float* skip_bias, const float* post1, const float* post1_bias,
                       const float* post2, const float* post2_bias, int Q, int precision, float* packed,
                       pwv_stream_t stream) {
@@ -692,6 +697,8 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
         lp.head_out[g] = a->head_out[g];
         PWV_CHECK_ARG(!a->x_first || a->causal_filter[g], "pwv_wavenet_layer_f32: x_first needs causal_filter for net %d", g);
         lp.cfilt[g] = a->causal_filter[g];
+        lp.fold0[g] = (a->x_first && a->precision == PWV_PREC_F16X3) ? a->first_fold[g] : nullptr;
+        PWV_CHECK_ARG((lp.fold0[g] == nullptr) == (lp.fold0[0] == nullptr), "pwv_wavenet_layer_f32: first_fold must be set for all nets or for none");
         PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_layer_f32: in-place layers are not supported (x[t-d] halo)");
         lp.x_in[g] = a->x_in[g];
         lp.x_out[g] = a->x_out[g];
@@ -866,7 +873,10 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
                 la.x_first = (two && grp == 1 && a->x_first_chain1) ? a->x_first_chain1 : a->x_first;
                 la.x_limit = a->x_limit;
                 la.range_flag = a->range_flag;
-                for (int i = 0; i < per_group; ++i) la.causal_filter[i] = a->causal_filter[two ? grp : i];
+                for (int i = 0; i < per_group; ++i) {
+                    la.causal_filter[i] = a->causal_filter[two ? grp : i];
+                    la.first_fold[i] = a->first_fold[two ? grp : i];
+                }
             }
             if (j == 0 && a->ev_begin[grp]) PWV_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin[grp], (hipStream_t)streams[grp]));
             const int rc = pwv_wavenet_layer_f32(&la, streams[grp]);

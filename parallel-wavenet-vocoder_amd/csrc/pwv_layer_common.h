@@ -49,6 +49,7 @@ struct LayerParams {
     long long* trace;   // debug builds only (-DPWV_TRACE): per-wave phase timestamps
     const float* x_first;                   // layer 0 without a materialised causal layer: the scalar input [rows] ...
     const float* cfilt[PWV_MAX_NETS];       // ... and each net's causal filter [2,1,64] (split-fp16 kernel only)
+    const float* fold0[PWV_MAX_NETS];       // ... optional (split-fp16 kernel): layer 0's folded fragments (pwv_pack_first_fold_f16x3)
     const float* packed_head[PWV_MAX_NETS]; // last layer with the head fused behind it (split-fp16 kernel only)
     float* head_out[PWV_MAX_NETS];
     int head_q;
@@ -288,6 +289,7 @@ int launch_head_f16x3(const HeadParams& hp, bool from_gated, int grid, hipStream
 int launch_pack_layer_f16x3(const float* filter, const float* gate, const float* dense, const float* dense_bias,
                             const float* skip, const float* skip_bias, const float* gc_filter, const float* gc_gate,
                             int with_skip, int cond_c, float* out, hipStream_t s);
+int launch_pack_first_fold_f16x3(const float* cf, const float* filter, const float* gate, float* out, hipStream_t s);
 int launch_pack_head_f16x3(const float* skip, const float* skip_bias, const float* post1, const float* post1_bias,
                            const float* post2, const float* post2_bias, int Q, float* out, hipStream_t s);
 

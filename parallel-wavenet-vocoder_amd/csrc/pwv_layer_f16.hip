@@ -30,9 +30,15 @@ namespace pwv {
 // exactly the three weight matrices (filter|gate 64 KB + skip 32 KB + postprocess1 64 KB = all 160 KB of the CU): the
 // small vectors (skip / postprocess1 biases, postprocess2) are read from global memory per unit like P, and units are
 // handed out statically (no room for a counter).
-template <bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
+//
+// FOLD (with FIRST): h[t] = x[t-1] w0 + x[t] w1 makes the filter|gate convolution of layer 0 a [4 -> 128] map of the scalars
+// x[t-d-1], x[t-d], x[t-1], x[t] (pwv_pack_first_fold_f16x3): ONE MFMA k-step (4 of its 16 k values used) instead of eight,
+// no LDS fragment reads and no operand splits for it.  The same function, rounded differently; the persistent kernel's
+// folded layer 0 (pwv_stack_persist.hip) performs exactly these operations, so the two stay bit-identical.
+template <bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false, bool FOLD = false>
 __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
     static_assert(!HEAD || (GATED && !SKIP && !COND && !FIRST), "HEAD: plain last layer only");
+    static_assert(!FOLD || FIRST, "FOLD: layer 0 of a scalar-input net only");
     constexpr int WAVES = 8;
     constexpr int kLds = HEAD ? kA1Size + kASSize + kHA1Size : layer_floats(SKIP, COND);
     constexpr int kCF = kLds + 4;           // FIRST: the causal filter [2][64] behind the unit counter
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         PWV_STAMP(2);
+        f16x8 fb_h = {0, 0, 0, 0, 0, 0, 0, 0}, fb_l = {0, 0, 0, 0, 0, 0, 0, 0};      // FOLD: the scalars as ONE B operand (k = 0..3, lower half)
         if constexpr (FIRST) {
             // rebuild this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; same operation order
             // as iaf_front_kernel: round(x[t-1] w0), then fma(x[t], w1, .)
@@ -181,15 +188,27 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             const bool has_prev = t >= p.dilation;
             // range guard (include/pwv_hip.h): every row is some lane's x[t]; NaN fails the comparison too
             if (p.range_flag && !(fabsf(x0) <= p.x_limit)) __hip_atomic_store(p.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if constexpr (FOLD) {
+                const float sc[4] = {xd1, xd0, x1v, x0};      // (x[t-d], x[t-d-1] are already zero left of the start)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = h == 0 ? sc[q] : 0.f;
+                    const _Float16 vh = (_Float16)v;
+                    fb_h[q] = vh;
+                    fb_l[q] = (_Float16)(v - (float)vh);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCF + 8 * g + 4 * h]);
                 const f32x4 w1 = *reinterpret_cast<const f32x4*>(&lds[kCF + 64 + 8 * g + 4 * h]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    rxc[4 * g + e] = fmaf(x0, w1[e], x1v * w0[e]);
-                    const float vb = fmaf(xd0, w1[e], xd1 * w0[e]);
-                    rxb[4 * g + e] = has_prev ? vb : 0.f;
+                    rxc[4 * g + e] = fmaf(x0, w1[e], x1v * w0[e]);      // (h[t]: the residual add needs it in every form)
+                    if constexpr (!FOLD) {
+                        const float vb = fmaf(xd0, w1[e], xd1 * w0[e]);
+                        rxb[4 * g + e] = has_prev ? vb : 0.f;
+                    }
                 }
             }
         }
@@ -197,10 +216,12 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         float xc[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) xc[i] = rxc[i];
-        split8<0>(rxb, bh[0], bl[0]);
-        split8<8>(rxb, bh[1], bl[1]);
-        split8<16>(rxb, bh[2], bl[2]);
-        split8<24>(rxb, bh[3], bl[3]);
+        if constexpr (!FOLD) {
+            split8<0>(rxb, bh[0], bl[0]);
+            split8<8>(rxb, bh[1], bl[1]);
+            split8<16>(rxb, bh[2], bl[2]);
+            split8<24>(rxb, bh[3], bl[3]);
+        }
         // x[t] (k-steps 4..7) is split under the first four MFMA groups of pair 0
 
         auto bxh = [&](int s) -> f16x8 { return bh[s]; };
@@ -213,6 +234,33 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         f16x8 oh[4], ol[4];      // gated output as B operand: k-step s <-> o tile s>>1, regs 8*(s&1)..+7
         f16x8 ah[4], al[4];
 
+        if constexpr (FOLD) {
+            // ---- layer 0, folded: the per-sample condition's GEMM (if any), then ONE k-step on the scalars ----------------
+            if constexpr (COND) {
+                first_frags<5, 2, 0, 2, 4>(AC, lane, ah, al);
+                gemm16<5, 2, 0, 2, 4>(AC, lane, acc, ah, al, bch, bcl, no_extra,
+                                      [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<5, 2, 1, 2, 4>(AC, lane, nh, nl); });
+                gemm16<5, 2, 1, 2, 4>(AC, lane, acc, ah, al, bch, bcl, no_extra, [](f16x8(&)[4], f16x8(&)[4]) {});
+            }
+            const f16x8* F0 = reinterpret_cast<const f16x8*>(p.fold0[net]);
+            f16x8 fh[4], fl[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                fh[it] = F0[it * 64 + lane];
+                fl[it] = F0[(4 + it) * 64 + lane];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[it], fb_h, acc[it], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[it], fb_l, acc[it], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[it], fb_h, acc[it], 0, 0, 0);
+            if constexpr (!GATED) first_frags<4, 2, 0, 1, 2>(A2, lane, ah, al);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = gate_act(acc[0][r], acc[2][r]);
+            split8<0>(o, oh[0], ol[0]);
+            split8<8>(o, oh[1], ol[1]);
+        } else {
         // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]) ----------------------------------------
         if constexpr (COND) {
             first_frags<5, 2, 0, 2, 4>(AC, lane, ah, al);
@@ -258,6 +306,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 if constexpr (!GATED) first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl);
                 else if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
             });
+        }
 
         PWV_STAMP(5);
         const int ooff = units_off(row, h, 64, u_begin);      // (rows past the end are never stored: `valid`)
@@ -639,6 +688,31 @@ __global__ void pack_layer_f16_kernel(const float* filter, const float* gate, co
     }
 }
 
+// pwv_pack_first_fold_f16x3: layer 0 of a scalar-input net, filter|gate folded onto the causal layer (modules.py:174-183 into
+// :216-222).  h[t] = x[t-1] w0 + x[t] w1, so F|G(h[t-d], h[t]) = M [x[t-d-1], x[t-d], x[t-1], x[t]]^T with the [128, 4] matrix
+// M[oc][2 tap + c] = sum_cin cf[c][cin] W[tap][cin][oc] (accumulated in fp64).  Output: the A fragments of ONE k-step,
+// [hi | lo][4 row tiles][64 lanes] f16x8, k values 0..3 used (lanes with h = 0), the rest zero.
+__global__ void pack_first_fold_f16_kernel(const float* __restrict__ cf, const float* __restrict__ filter, const float* __restrict__ gate,
+                                           f16x8* __restrict__ out) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * 4 * 64) return;
+    const int comp = u >> 8, it = (u >> 6) & 3, lane = u & 63, h = lane >> 5, i = lane & 31;
+    const int oc = 32 * it + i;
+    float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (h == 0) {
+        for (int q = 0; q < 4; ++q) {
+            const int tap = q >> 1, c = q & 1;
+            double acc = 0.0;
+            for (int cin = 0; cin < 64; ++cin) {
+                const float wv = oc < 64 ? filter[(tap * 64 + cin) * 64 + oc] : gate[(tap * 64 + cin) * 64 + oc - 64];
+                acc += (double)cf[c * 64 + cin] * (double)wv;
+            }
+            w[q] = (float)((double)(oc < 64 ? kFScale : kGScale) * acc);
+        }
+    }
+    put_split(&out[u], comp, w);
+}
+
 __global__ void pack_head_f16_kernel(const float* skip, const float* skip_bias, const float* post1,
                                      const float* post1_bias, const float* post2, const float* post2_bias, int Q,
                                      float* out, int total_floats) {
@@ -703,9 +777,9 @@ __global__ void pack_head_f16_kernel(const float* skip, const float* skip_bias, 
     if (base * 4 < total_floats) o32[base] = v;
 }
 
-template <bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
+template <bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false, bool FOLD = false>
 static int launch16(const LayerParams& lp, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED, FIRST, HEAD>), dim3(grid), dim3(512), 0, s, lp);
+    hipLaunchKernelGGL((layer_f16x3_kernel<SKIP, COND, GATED, FIRST, HEAD, FOLD>), dim3(grid), dim3(512), 0, s, lp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 layer kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
@@ -720,6 +794,10 @@ int launch_layer_f16x3(const LayerParams& lp, bool skip, bool cond, bool gated, 
     }
     if (lp.x_first) {
         if (skip) return set_error(PWV_EINVAL, "x_first (layer 0 without a materialised causal layer) does not support skip accumulation");
+        if (lp.fold0[0]) {      // layer 0 in its folded form
+            if (cond) return gated ? launch16<false, true, true, true, false, true>(lp, grid, s) : launch16<false, true, false, true, false, true>(lp, grid, s);
+            return gated ? launch16<false, false, true, true, false, true>(lp, grid, s) : launch16<false, false, false, true, false, true>(lp, grid, s);
+        }
         if (cond) return gated ? launch16<false, true, true, true>(lp, grid, s) : launch16<false, true, false, true>(lp, grid, s);
         return gated ? launch16<false, false, true, true>(lp, grid, s) : launch16<false, false, false, true>(lp, grid, s);
     }
@@ -749,6 +827,13 @@ int launch_pack_layer_f16x3(const float* filter, const float* gate, const float*
                        dense_bias, skip, skip_bias, gc_filter, gc_gate, with_skip, cond_c, out, units);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "f16x3 pack launch failed: %s", hipGetErrorString(e));
+    return PWV_OK;
+}
+
+int launch_pack_first_fold_f16x3(const float* cf, const float* filter, const float* gate, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(pack_first_fold_f16_kernel, dim3(2), dim3(256), 0, s, cf, filter, gate, reinterpret_cast<f16x8*>(out));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PWV_EHIP, "first-fold pack launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
 }
 

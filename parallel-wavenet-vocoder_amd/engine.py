@@ -50,6 +50,9 @@ TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
 HOIST_P = os.environ.get('PWV_HOIST_P', '1') != '0'
 # PWV_FUSE_FIRST=0: materialise the causal layer with the front kernel even where layer 0 could rebuild it (A/B knob)
 FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
+# PWV_FOLD_FIRST=0: layer 0 of the persistent launch runs its filter|gate GEMM on the rebuilt causal-layer rows (eight MFMA
+# k-steps) instead of on the four scalars they are a function of (one k-step); default: folded (split-fp16 path)
+FOLD_FIRST = os.environ.get('PWV_FOLD_FIRST', '1') != '0'
 # PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
 FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
 # The residual layers 1 .. L-2 of a stack as ONE persistent launch (csrc/pwv_stack_persist.hip, bit-identical results)
@@ -413,6 +416,18 @@ class NetPlan:
         self.f16x3_ok, self.x_limit = True, 3.0e38
         if precision == _lib.PREC_F16X3:
             self._range_analysis(net, L, use_skip, cond_mode)
+        # split-fp16 path, scalar-input nets: layer 0's filter|gate GEMM folded onto the four scalars it is a function of
+        # (pwv_persist_args.first_fold); the scalars themselves are then fp16 operands, hence the extra bound on them
+        self.first_fold = None
+        if (precision == _lib.PREC_F16X3 and FOLD_FIRST and self.f16x3_ok and net.in_channels == 1 and net.filter_width == 2
+                and net.residual_channels == 64 and net.dilation_channels == 64 and self.causal_bias is None):
+            v0 = self._lv(0)
+            ff = torch.empty((_lib.FIRST_FOLD_FLOATS,), dtype=torch.float32, device=dev)
+            check(lib.pwv_pack_first_fold_f16x3(_ptr(self.causal_filter), _ptr(v0['filter']), _ptr(v0['gate']), _ptr(ff), s),
+                  'pwv_pack_first_fold_f16x3')
+            if bool(torch.isfinite(ff.view(torch.float16).float()).all()):
+                self.first_fold = ff
+                self.x_limit = min(self.x_limit, F16_LIMIT)
 
     def _range_analysis(self, net, L, use_skip, cond_mode):
         """Bound every operand the split-fp16 kernels convert to fp16 (weights after the exp2 scale folding; the residual
@@ -517,6 +532,9 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
             pa.x_first, pa.x_limit, pa.range_flag = _ptr(x_first), x_limit, range_flag_ptr()
             for g in range(G):
                 pa.causal_filter[g] = plans[g].causal_filter.data_ptr()
+            if FOLD_FIRST and all(p.first_fold is not None for p in plans):
+                for g in range(G):
+                    pa.first_fold[g] = plans[g].first_fold.data_ptr()
         pa.packed_layer_stride = stride
         pa.proj_row_stride = row_stride
         pa.N, pa.T = n, t
@@ -682,6 +700,8 @@ def run_flow_chain(flow_nets: Sequence, x: torch.Tensor, cond, precision: Option
             sa.packed_head[g] = plans[g].packed_head.data_ptr()
             sa.out[g] = outs[g].data_ptr()
             sa.causal_filter[g] = plans[g].causal_filter.data_ptr()
+            if FOLD_FIRST and all(p.first_fold is not None for p in plans):
+                sa.first_fold[g] = plans[g].first_fold.data_ptr()
         sa.packed_layer_stride = plans[0].layer_floats
         sa.proj_row_stride = projs[0].stride(0) if mode == 'frames' else 128 * L
         sa.Q, sa.N, sa.T = 1, n, t
@@ -901,6 +921,9 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
         sa.range_flag = range_flag_ptr()
         for g in range(G):
             sa.causal_filter[g] = plans[g].causal_filter.data_ptr()
+        if FOLD_FIRST and all(p.first_fold is not None for p in plans):
+            for g in range(G):
+                sa.first_fold[g] = plans[g].first_fold.data_ptr()
     streams = (c_void_p * 2)(side[0].cuda_stream if two else s.value, side[1].cuda_stream if two else None)
     evs = []
     if EVENT_LOG is not None and L > 1:

@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 D10 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
 
 
-def _nets(gpu, L, G, seed=3):
+def _nets(gpu, L, G, seed=3, cond_channels=80):
     import torch
     from pwv_amd import engine
     from pwv_amd.modules import WaveNet
     from pwv_amd.variables import VariableStore
     store = VariableStore(device=gpu, seed=seed)
     kw = dict(batch_size=1, dilations=(D10 * 3)[:L], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
-              quantization_channels=1, use_biases=True, condition_channels=80, use_skip_connection=False, is_training=False, store=store)
+              quantization_channels=1, use_biases=True, condition_channels=cond_channels, use_skip_connection=False, is_training=False, store=store)
     nets = [WaveNet(name='n%d' % g, **kw) for g in range(G)]
     return store, nets
 
@@ -33,9 +33,9 @@ def _nets(gpu, L, G, seed=3):
 @pytest.fixture()
 def persist_knobs():
     from pwv_amd import engine
-    saved = (engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS)
+    saved = (engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS, engine.FOLD_FIRST)
     yield engine
-    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS = saved
+    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS, engine.FOLD_FIRST = saved
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
@@ -75,6 +75,46 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
         engine.EVENT_LOG = None
     runs = engine._persist_runs(L, 0)       # (scalar-input nets: the launch starts with the net's layer 0)
     assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 1)      # it really was persistent
+
+
+@pytest.mark.parametrize('n,t,L,G,cond', [(1, 16000, 10, 2, 'frames'), (3, 2400, 6, 1, 'frames'), (2, 4000, 5, 2, 'none'), (1, 1234, 3, 2, 'samples')])
+def test_folded_layer0_is_the_same_function_on_every_path(gpu, persist_knobs, n, t, L, G, cond):
+    """Split-fp16 path, scalar-input nets: layer 0's filter|gate convolution folded onto the four scalars it is a function
+    of (pwv_pack_first_fold_f16x3; the default) -- the persistent launch and the per-layer FIRST kernels (also with a
+    per-sample condition) perform the same operations, so they agree bit for bit, and the folded result stays within the
+    path's tolerance of the unfolded one (h[t] = x[t-1] w0 + x[t] w1 evaluated first, modules.py:179-180)."""
+    import torch
+    engine = persist_knobs
+    store, nets = _nets(gpu, L, G, cond_channels=None if cond == 'none' else 80)
+    g = torch.Generator().manual_seed(n * 11 + L)
+    x = torch.randn((n, t, 1), generator=g).to(gpu)
+    if cond == 'frames':
+        c = engine.RepeatedCondition(torch.rand((n, t // 80 + 1, 80), generator=g).to(gpu), 80, 40, t)
+    elif cond == 'samples':
+        c = (torch.rand((n, t, 80), generator=g) * 2 - 1).to(gpu)
+    else:
+        c = None
+    engine.run_nets(nets, x, c, precision='f16x3')  # creates the variables
+    for name in list(store.vars):
+        if store.vars[name].dim() == 1:
+            store.vars[name].normal_(0, 0.1)
+    store.version += 1
+    engine.FOLD_FIRST = True
+    engine.run_nets(nets, x, c, precision='f16x3')       # (the plans are made here, with the folded fragments)
+    res = {}
+    for fold in (False, True):
+        for persist in (False, True):
+            engine.FOLD_FIRST, engine.PERSIST = fold, persist
+            res[fold, persist] = [o.clone() for o in engine.run_nets(nets, x, c, precision='f16x3')]
+            torch.cuda.synchronize()
+            assert engine.persist_status() == 0
+    mode = 'none' if c is None else ('frames' if cond == 'frames' else 'samples')
+    assert all(engine.get_plan(net, mode, engine.PRECISIONS['f16x3']).first_fold is not None for net in nets)
+    for k in range(G):
+        assert torch.equal(res[False, False][k], res[False, True][k]) and torch.equal(res[True, False][k], res[True, True][k])
+        a, b = res[False, False][k], res[True, False][k]
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+        assert not torch.equal(a, b)           # (it really was another evaluation order)
 
 
 def test_whole_model_persistent_eager_and_graph_replay(gpu, persist_knobs):
