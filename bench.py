@@ -533,8 +533,15 @@ def main():
                         if k in tj:
                             roof[k] = tj[k]
             result['roofline'] = roof
-            result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS,
-                                       'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)', 'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
+            # issued: three fp16 MFMAs per algorithmic one -- except in a net's layer 0 when it runs folded onto its four input
+            # scalars (engine.FOLD_FIRST): ONE k-step of 16 for the filter|gate convolution instead of eight
+            folded = args.precision == 'f16x3' and engine.FOLD_FIRST and timing['first_net_layers'] > 0
+            first_issued = 3 * 2 * (16 * 128 + 64 * 64) if folded else 3 * LAYER_FLOP_PER_SAMPLE
+            issued_tf = rows * ((timing['net_layers'] - timing['first_net_layers']) * 3 * LAYER_FLOP_PER_SAMPLE
+                                + timing['first_net_layers'] * first_issued) / (timing['total_ms'] * 1e-3) / 1e12
+            roof['first_layer'] = 'folded onto its four input scalars (one MFMA k-step for filter|gate)' if folded else 'as every other layer'
+            result['roofline_mfma'] = {'bound': 'mfma', 'achieved': issued_tf, 'peak': PEAK_F16_MFMA_TFLOPS,
+                                       'unit': 'TFLOP/s (fp16 MFMA FLOPs issued: 3x algorithmic, a folded layer 0 less)', 'frac': issued_tf / PEAK_F16_MFMA_TFLOPS}
         elif timing is not None:
             layer_ms, nets_per_launch = timing['layer_ms'], timing['nets_per_launch']
             per_sample = 1 if hp.model.cond_upsample_method == 'transposed_conv' else 0

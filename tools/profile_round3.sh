@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 profile set (run on the GPU box through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'tools/profile_round3.sh r03_d'
+#   gpurun --timeout 1500 -- 'tools/profile_round3.sh r03_e'
 # Raw rocprofv3 output stays in /tmp on the box; the summaries land in gpurun_out/<tag>_profiles/ (the only part that travels
 # back) -- copy them into profiles/.  Counter passes are separate runs with --kernel-trace only (never with other trace domains).
 set -u

@@ -4,6 +4,7 @@ bench line (value, roofline) + PMC traffic (2 x FETCH_SIZE + WRITE_SIZE, the gfx
 matrix-pipe busy share of the dominant kernel.  usage: profile_round3_summarize.py OUTDIR TMPDIR"""
 import collections
 import csv
+import re
 import json
 import os
 import sys
@@ -48,8 +49,13 @@ for name, label in (('c3', 'C3 default model 1 x 160000 (headline)'), ('c4', 'C4
     traffic = (2 * f + w) * 1024.0                    # bytes over the launches of the two timed eager steps (+1 warm-up)
     # algorithmic bytes of the same launches: the bench line's per-net-layer (or per-launch) figure x what those launches ran
     if 'alg_bytes_per_net_layer' in roof:
-        # persistent launches: every MFMA count / 120 = one 32-row unit of one net-layer
+        # persistent launches: every MFMA count / 120 = one 32-row unit of one net-layer -- except the units of a net's layer 0
+        # when it runs folded onto its four input scalars (36 MFMAs): every launch of the bench configurations starts with one
         units = mfma / 120.0
+        if str(roof.get('first_layer', '')).startswith('folded'):
+            nets = int(re.search(r'x (\d+) nets per launch', roof['kernel']).group(1))
+            first_units = nf * nets * (b['config']['utterances_per_gpu'] * b['config']['samples_per_utterance'] + 31) // 32
+            units = (mfma + 84.0 * first_units) / 120.0
         alg = units * 32 * (roof['alg_bytes_per_net_layer'] / (b['config']['utterances_per_gpu'] * b['config']['samples_per_utterance']))
     else:
         alg = roof['alg_bytes_per_launch'] * nf
