@@ -228,7 +228,7 @@ typedef struct pwv_layer_args {
      * traffic per sample for this layer and no front launch.  x_first is [N*T] float32 (the flow's input). */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];   /* [2,1,64] each */
-    /* optional, PWV_PREC_F16X3 with x_first: pwv_pack_first_fold_f16x3's output per net (all nets or none).  Layer 0's
+    /* optional, PWV_PREC_F16X3 / PWV_PREC_F32 with x_first: pwv_pack_first_fold_f16x3's / _f32's output per net (all nets or none).  Layer 0's
      * filter|gate convolution then runs on the four scalars x[t-d-1], x[t-d], x[t-1], x[t] themselves -- one MFMA k-step
      * instead of eight: the same function (h[t] is linear in x[t-1], x[t]), rounded differently: within the path's
      * tolerance of the unfolded form, not bit-identical to it.  pwv_persist_args.first_fold does exactly the same. */
@@ -263,6 +263,8 @@ size_t pwv_head_packed_floats(int Q);
  * The fold is accumulated in fp64. */
 #define PWV_FIRST_FOLD_FLOATS 2048
 int pwv_pack_first_fold_f16x3(const float* causal_filter, const float* filter, const float* gate, float* folded, pwv_stream_t stream);
+/* the same fold for PWV_PREC_F32 (two fp32 MFMA k-steps per row tile instead of 64): 1024 floats of `folded` are written */
+int pwv_pack_first_fold_f32(const float* causal_filter, const float* filter, const float* gate, float* folded, pwv_stream_t stream);
 
 /* skip [1,64,128], skip_bias [128]/NULL, post1 [1,128,128], post1_bias [128]/NULL,
  * post2 [1,128,Q], post2_bias [Q]/NULL */
@@ -436,7 +438,7 @@ typedef struct pwv_persist_args {
     const float* causal_filter[PWV_MAX_NETS];
     float x_limit;                                /* range guard on x_first (pwv_layer_args.x_limit / range_flag) */
     int* range_flag;
-    /* optional, with x_first and PWV_PREC_F16X3: pwv_pack_first_fold_f16x3's output per net (all nets or none).  Layer 0's
+    /* optional, with x_first: pwv_pack_first_fold_f16x3's (PWV_PREC_F16X3) or pwv_pack_first_fold_f32's (PWV_PREC_F32) output per net (all nets or none).  Layer 0's
      * filter|gate GEMM then runs on the four scalars x[t-d-1], x[t-d], x[t-1], x[t] themselves (one MFMA k-step instead of
      * eight): the same function (h[t] is linear in x[t-1], x[t]), rounded differently -- within the path's tolerance of the
      * unfolded form, not bit-identical to it */

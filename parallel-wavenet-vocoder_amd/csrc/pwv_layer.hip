@@ -100,8 +100,11 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
 // HEAD  (plain gated last layer, 8 waves): head_f32_kernel<true>'s arithmetic runs behind the gate on the registers the
 //   gated output was accumulated in; LDS holds exactly filter|gate + skip + postprocess1 = 160 KB, so the small vectors
 //   come from global memory and units are handed out statically (no room for the counter).
-template <int WAVES, bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
+// FOLD (with FIRST): layer 0's filter|gate convolution on the four scalars x[t-d-1], x[t-d], x[t-1], x[t] themselves
+//   (pwv_pack_first_fold_f32; see layer_f16x3_kernel): two fp32 MFMA k-steps per row tile instead of 64.
+template <int WAVES, bool SKIP, bool COND, bool GATED, bool FIRST = false, bool HEAD = false, bool FOLD = false>
 __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams p) {
+    static_assert(!FOLD || FIRST, "FOLD: layer 0 of a scalar-input net only");
     static_assert(!(FIRST || HEAD) || WAVES == 8, "FIRST / HEAD: 8-wave kernels only");
     static_assert(!HEAD || (GATED && !SKIP && !COND && !FIRST), "HEAD: plain last layer only");
     static_assert(!FIRST || !SKIP, "FIRST: no skip accumulation");
@@ -171,8 +174,11 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
         const int next = PREFETCH ? unit + WAVES : 0;
         if constexpr (!PREFETCH) load_tile<SKIP, COND, FIRST>(p, net, unit, lane, cur, skip_load);
         float first_x0 = 0.f, first_x1 = 0.f;      // FIRST: x[t], x[t-1]
+        float fold_b0 = 0.f, fold_b1 = 0.f;        // FOLD: the B values of the two k-steps
         (void)first_x0;
         (void)first_x1;
+        (void)fold_b0;
+        (void)fold_b1;
         if constexpr (FIRST) {
             // this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; same operation order as
             // iaf_front_kernel: round(x[t-1] w0), then fma(x[t], w1, .)
@@ -180,8 +186,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
             first_x0 = x0;
             first_x1 = x1v;
             const bool has_prev = cur.t >= p.dilation;
+            if constexpr (FOLD) {      // (x[t-d], x[t-d-1] are already zero left of the start)
+                fold_b0 = h ? xd0 : xd1;      // k = 0, 1
+                fold_b1 = h ? x0 : x1v;       // k = 2, 3
+            }
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < (FOLD ? 0 : 8); ++g) {
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lds[kCF + 8 * g + 4 * h]);
                 const f32x4 w1 = *reinterpret_cast<const f32x4*>(&lds[kCF + 64 + 8 * g + 4 * h]);
 #pragma unroll
@@ -206,6 +216,32 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
         auto bc = [&](int ks) -> float { return cur.cd[COND ? ks : 0]; };
         // pair 0 = row tiles (0: F[0:32], 2: G[0:32]); pair 1 = (1: F[32:64], 3: G[32:64]).
         // pair 0 is gated on the VALU while pair 1's MFMAs run.
+        if constexpr (FOLD) {
+            // ---- layer 0, folded: the per-sample condition's GEMM (if any), then two k-steps on the scalars ------------------
+            if constexpr (COND) {
+                a[0] = frag(lds, kAC, 0, NC8, 0, lane);
+                a[1] = frag(lds, kAC, 2, NC8, 0, lane);
+                gemm_groups<NC8, 2, 0, 2>(lds, kAC, lane, acc, a, bc, no_extra, [&](f32x4(&n)[4]) {
+                    n[0] = frag(lds, kAC, 1, NC8, 0, lane);
+                    n[1] = frag(lds, kAC, 3, NC8, 0, lane);
+                });
+                gemm_groups<NC8, 2, 1, 2>(lds, kAC, lane, acc, a, bc, no_extra, [](f32x4(&)[4]) {});
+            }
+            const f32x4* F0 = reinterpret_cast<const f32x4*>(p.fold0[net]);
+            f32x4 ff[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ff[it] = F0[it * 64 + lane];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ff[it][0], fold_b0, acc[it], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ff[it][1], fold_b1, acc[it], 0, 0, 0);
+            if constexpr (!GATED) {
+                a[0] = frag(lds, kA2, 0, 8, 0, lane);
+                a[1] = frag(lds, kA2, 1, 8, 0, lane);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[g] = gate_act(acc[0][g], acc[2][g]);
+        } else {
         if constexpr (COND) {
             a[0] = frag(lds, kAC, 0, NC8, 0, lane);
             a[1] = frag(lds, kAC, 2, NC8, 0, lane);
@@ -250,6 +286,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
                     for (int i = 0; i < 4; ++i) n[i] = frag(lds, kHS, i, 8, 0, lane);
                 }
             });
+        }
 
         // next tile's operands: in flight during GEMM2 / skip GEMM / stores
         TileRegs<SKIP, COND> nx;   // rows past the end are clamped inside load_tile
@@ -496,6 +533,25 @@ __global__ __launch_bounds__(256) void head_f32_kernel(const HeadParams p) {
 // --------------------------------------------------------------------------------------
 // weight packing (device-side gathers from TensorFlow layouts)
 // --------------------------------------------------------------------------------------
+// pwv_pack_first_fold_f32 (see pack_first_fold_f16_kernel): [4 row tiles][64 lanes] f32x4 = {M[oc][h], M[oc][2 + h], 0, 0},
+// the A values of the two fp32 MFMA k-steps (k = h and k = 2 + h) of lane (i, h), oc = 32 it + i
+__global__ void pack_first_fold_f32_kernel(const float* __restrict__ cf, const float* __restrict__ filter, const float* __restrict__ gate,
+                                           f32x4* __restrict__ out) {
+    const int u = threadIdx.x;      // (it, lane)
+    const int it = u >> 6, lane = u & 63, h = lane >> 5, oc = 32 * it + (lane & 31);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 2; ++e) {
+        const int k = 2 * e + h, tap = k >> 1, c = k & 1;
+        double acc = 0.0;
+        for (int cin = 0; cin < 64; ++cin) {
+            const float wv = oc < 64 ? filter[(tap * 64 + cin) * 64 + oc] : gate[(tap * 64 + cin) * 64 + oc - 64];
+            acc += (double)cf[c * 64 + cin] * (double)wv;
+        }
+        v[e] = (float)((double)(oc < 64 ? kFScale : kGScale) * acc);
+    }
+    out[u] = v;
+}
+
 __global__ void pack_layer_kernel(const float* filter, const float* gate, const float* dense,
                                   const float* dense_bias, const float* skip, const float* skip_bias,
                                   const float* gc_filter, const float* gc_gate, int with_skip, int cond_c,
@@ -604,9 +660,9 @@ static int launch_layer(const LayerParams& lp, int per_net4, int per_net8, hipSt
 }
 
 // the two buffer-removing variants (always 8 waves)
-template <bool COND, bool GATED, bool FIRST, bool HEAD>
+template <bool COND, bool GATED, bool FIRST, bool HEAD, bool FOLD = false>
 static int launch_layer_fused(const LayerParams& lp, int per_net8, hipStream_t s) {
-    hipLaunchKernelGGL((layer_f32_kernel<8, false, COND, GATED, FIRST, HEAD>), dim3(per_net8 * lp.G), dim3(512), 0, s, lp);
+    hipLaunchKernelGGL((layer_f32_kernel<8, false, COND, GATED, FIRST, HEAD, FOLD>), dim3(per_net8 * lp.G), dim3(512), 0, s, lp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "layer kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
@@ -655,6 +711,14 @@ int pwv_pack_layer_f32(const float* filter, const float* gate, const float* dens
     return PWV_OK;
 }
 
+int pwv_pack_first_fold_f32(const float* causal_filter, const float* filter, const float* gate, float* folded, pwv_stream_t stream) {
+    PWV_CHECK_ARG(causal_filter && filter && gate && folded, "pwv_pack_first_fold_f32: NULL pointer");
+    hipLaunchKernelGGL(pack_first_fold_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, causal_filter, filter, gate,
+                       reinterpret_cast<f32x4*>(folded));
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
 int pwv_pack_first_fold_f16x3(const float* causal_filter, const float* filter, const float* gate, float* folded, pwv_stream_t stream) {
     PWV_CHECK_ARG(causal_filter && filter && gate && folded, "pwv_pack_first_fold_f16x3: NULL pointer");
     return launch_pack_first_fold_f16x3(causal_filter, filter, gate, folded, (hipStream_t)stream);
@@ -697,7 +761,7 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
         lp.head_out[g] = a->head_out[g];
         PWV_CHECK_ARG(!a->x_first || a->causal_filter[g], "pwv_wavenet_layer_f32: x_first needs causal_filter for net %d", g);
         lp.cfilt[g] = a->causal_filter[g];
-        lp.fold0[g] = (a->x_first && a->precision == PWV_PREC_F16X3) ? a->first_fold[g] : nullptr;
+        lp.fold0[g] = (a->x_first && a->precision != PWV_PREC_F16) ? a->first_fold[g] : nullptr;
         PWV_CHECK_ARG((lp.fold0[g] == nullptr) == (lp.fold0[0] == nullptr), "pwv_wavenet_layer_f32: first_fold must be set for all nets or for none");
         PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_layer_f32: in-place layers are not supported (x[t-d] halo)");
         lp.x_in[g] = a->x_in[g];
@@ -762,6 +826,10 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
         return launch_layer_h16(lp, cond, gated, want < nt4 ? want : nt4, s);
     }
     if (lp.packed_head[0]) return launch_layer_fused<false, true, false, true>(lp, g8, s);
+    if (lp.x_first && lp.fold0[0]) {
+        if (cond) return gated ? launch_layer_fused<true, true, true, false, true>(lp, g8, s) : launch_layer_fused<true, false, true, false, true>(lp, g8, s);
+        return gated ? launch_layer_fused<false, true, true, false, true>(lp, g8, s) : launch_layer_fused<false, false, true, false, true>(lp, g8, s);
+    }
     if (lp.x_first) {
         if (cond) return gated ? launch_layer_fused<true, true, true, false>(lp, g8, s) : launch_layer_fused<true, false, true, false>(lp, g8, s);
         return gated ? launch_layer_fused<false, true, true, false>(lp, g8, s) : launch_layer_fused<false, false, true, false>(lp, g8, s);

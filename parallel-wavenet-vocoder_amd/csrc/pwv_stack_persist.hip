@@ -77,7 +77,7 @@ struct PersistParams {
     int dil[kMaxPLayers];
     const float* x_first;                  // != NULL: the run starts with the net's layer 0, which rebuilds the causal layer from the scalar input
     const float* cfilt[PWV_MAX_NETS];      // ... and each net's causal filter [2,1,64]
-    const float* fold0[PWV_MAX_NETS];      // split-fp16 path, optional: layer 0's filter|gate GEMM folded onto the four scalars (pwv_pack_first_fold_f16x3)
+    const float* fold0[PWV_MAX_NETS];      // optional: layer 0's filter|gate GEMM folded onto the four scalars (pwv_pack_first_fold_f16x3 / _f32)
     float x_limit;                         // range guard of the split-fp16 arithmetic on x_first (include/pwv_hip.h)
     int* range_flag;
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
@@ -396,72 +396,84 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     const long long pt_start_rt = __builtin_amdgcn_s_memrealtime();
     pt_acc[7] = pt_start;
 #endif
-    // ---- layer 0 in its folded form (split-fp16 path, pwv_persist_args.first_fold), a loop of its own in front of the general one.
+    // ---- layer 0 in its folded form (pwv_persist_args.first_fold), a loop of its own in front of the general one.
     // h[t] = x[t-1] w0 + x[t] w1 (modules.py:179-180) makes filter|gate(h[t-d], h[t]) a [4 -> 128] map of the scalars
-    // x[t-d-1], x[t-d], x[t-1], x[t]: ONE MFMA k-step (4 of its 16 k values used) instead of eight, no LDS fragment reads, no
-    // operand splits.  Layer 0 depends on nothing inside the launch (its input was complete before it started and the ring
-    // slot it writes has no earlier reader), so this loop never waits; tasks are layer-major, so it ends when the wave's next
-    // task is a layer-1 one, and the general loop's first-task code takes over.  (As a branch INSIDE the general loop the two
-    // accumulator sets cost it 60-80 spilled registers.)
-    if constexpr (!F32) {
-        if (p.x_first && p.fold0[net]) {
-            const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + kA1Size);      // layer 0's dense matrix: slot 0
-            const float* bias = lds + kBiasF + h * 32;
-            const char* F0 = reinterpret_cast<const char*>(p.fold0[net]);
-            const float* lastfrag = packed_n + kSlot + lane * 4;
-            const int d = dil_of(0);
-            const int dn = dil_of(1 < L ? 1 : 0);
-            typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
-            const lds_f4_t cfb = (lds_f4_t)(lds + kCfF + 4 * h);
-            while (u >= 0 && j == 0) {
-                int row, rc, nn, t;
-                bool valid;
-                unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
-                // the four scalars (zero left of the utterance start), the P row, the folded fragments, the dense tail
-                const float* x1 = p.x_first;
-                const bool has_prev = t >= d;
-                const float x0 = x1[rc];
-                const float x1v = t >= 1 ? x1[rc - (t >= 1 ? 1 : 0)] : 0.f;
-                const float xd0 = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f;
-                const float xd1 = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
-                f32x16 acc[4];
-                {
-                    int prow = 0;
-                    if (p.cond_hop > 0) prow = nn * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
-                    const float* pr = proj_n + (size_t)prow * p.proj_row_stride + h * 64;
+    // x[t-d-1], x[t-d], x[t-1], x[t]: ONE split-fp16 MFMA k-step (4 of its 16 k values used) instead of eight -- two fp32
+    // k-steps instead of 64 -- with no LDS fragment reads and no operand splits.  Layer 0 depends on nothing inside the launch
+    // (its input was complete before it started and the ring slot it writes has no earlier reader), so this loop never waits;
+    // tasks are layer-major, so it ends when the wave's next task is a layer-1 one, and the general loop's first-task code
+    // takes over.  (As a branch INSIDE the general loop the two accumulator sets cost it 60-80 spilled registers.)
+    if (p.x_first && p.fold0[net]) {
+        const float* Af = lds;                                                    // layer 0's weights: slot 0
+        const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + kA1Size);
+        (void)Af;
+        (void)A2;
+        const float* bias = lds + kBiasF + h * 32;
+        const char* F0 = reinterpret_cast<const char*>(p.fold0[net]);
+        const float* lastfrag = packed_n + kSlot + lane * 4;
+        const int d = dil_of(0);
+        const int dn = dil_of(1 < L ? 1 : 0);
+        typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
+        const lds_f4_t cfb = (lds_f4_t)(lds + kCfF + 4 * h);
+        while (u >= 0 && j == 0) {
+            int row, rc, nn, t;
+            bool valid;
+            unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+            // the four scalars (zero left of the utterance start), the P row, the folded fragments, the dense tail
+            const float* x1 = p.x_first;
+            const bool has_prev = t >= d;
+            const float x0 = x1[rc];
+            const float x1v = t >= 1 ? x1[rc - (t >= 1 ? 1 : 0)] : 0.f;
+            const float xd0 = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f;
+            const float xd1 = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
+            f32x16 acc[4];
+            {
+                int prow = 0;
+                if (p.cond_hop > 0) prow = nn * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
+                const float* pr = proj_n + (size_t)prow * p.proj_row_stride + h * 64;
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
+                for (int it = 0; it < 4; ++it)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
-                        }
-                }
-                f16x8 fh[4], fl[4];
+                        for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
+                    }
+            }
+            f16x8 fh[4], fl[4];      // split-fp16: [hi | lo][4 row tiles][64 lanes] f16x8
+            f32x4 ff[4];             // fp32: [4 row tiles][64 lanes] {k = h, k = 2 + h, 0, 0}
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < 4; ++it) {
+                if constexpr (F32) {
+                    ff[it] = *reinterpret_cast<const f32x4*>(F0 + it * 1024 + lane * 16);
+                } else {
                     fh[it] = *reinterpret_cast<const f16x8*>(F0 + it * 1024 + lane * 16);
                     fl[it] = *reinterpret_cast<const f16x8*>(F0 + (4 + it) * 1024 + lane * 16);
                 }
-                const f16x8 lf = *reinterpret_cast<const f16x8*>(lastfrag);
-                int j2 = 0;
-                const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);
-                // drain (the loads above, the previous unit's stores), publish that unit, claim the task after the next
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                publish();
-                if (u2 >= 0) claim_v = claim();
-                if (p.range_flag && !(fabsf(x0) <= p.x_limit)) __hip_atomic_store(p.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                f16x8 b_h = {0, 0, 0, 0, 0, 0, 0, 0}, b_l = {0, 0, 0, 0, 0, 0, 0, 0};      // k = 0..3: lanes of the lower half
-                {
-                    const float sc[4] = {xd1, xd0, x1v, x0};
+            }
+            const f32x4 lf32 = *reinterpret_cast<const f32x4*>(lastfrag);      // (16 bytes either way)
+            int j2 = 0;
+            const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);
+            // drain (the loads above, the previous unit's stores), publish that unit, claim the task after the next
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish();
+            if (u2 >= 0) claim_v = claim();
+            if (p.range_flag && !(fabsf(x0) <= p.x_limit)) __hip_atomic_store(p.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if constexpr (F32) {
+                const float b0 = h ? xd0 : xd1, b1 = h ? x0 : x1v;      // k = 0, 1 | k = 2, 3
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = h == 0 ? sc[q] : 0.f;
-                        const _Float16 vh = (_Float16)v;
-                        b_h[q] = vh;
-                        b_l[q] = (_Float16)(v - (float)vh);
-                    }
+                for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ff[it][0], b0, acc[it], 0, 0, 0);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ff[it][1], b1, acc[it], 0, 0, 0);
+            } else {
+                f16x8 b_h = {0, 0, 0, 0, 0, 0, 0, 0}, b_l = {0, 0, 0, 0, 0, 0, 0, 0};      // k = 0..3: lanes of the lower half
+                const float sc[4] = {xd1, xd0, x1v, x0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = h == 0 ? sc[q] : 0.f;
+                    const _Float16 vh = (_Float16)v;
+                    b_h[q] = vh;
+                    b_l[q] = (_Float16)(v - (float)vh);
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[it], b_h, acc[it], 0, 0, 0);
@@ -469,27 +481,36 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[it], b_l, acc[it], 0, 0, 0);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[it], b_h, acc[it], 0, 0, 0);
-                // GEMM2's accumulator starts at h[t] + dense_bias; h[t] with the operations of iaf_front_kernel (same bits as unfolded)
-                f32x16 acc2[2];
+            }
+            // GEMM2's accumulator starts at h[t] + dense_bias; h[t] with the operations of iaf_front_kernel (same bits as unfolded)
+            f32x16 acc2[2];
 #pragma unroll
-                for (int it = 0; it < 2; ++it)
+            for (int it = 0; it < 2; ++it)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 w0 = cfb[2 * (4 * it + q)];
-                        const f32x4 w1 = cfb[16 + 2 * (4 * it + q)];
-                        const f32x4 bd = *reinterpret_cast<const f32x4*>(bias + it * 16 + q * 4);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w0 = cfb[2 * (4 * it + q)];
+                    const f32x4 w1 = cfb[16 + 2 * (4 * it + q)];
+                    const f32x4 bd = *reinterpret_cast<const f32x4*>(bias + it * 16 + q * 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = fmaf(x0, w1[e], x1v * w0[e]) + bd[e];
-                    }
+                    for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = fmaf(x0, w1[e], x1v * w0[e]) + bd[e];
+                }
+            float o[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[r] = gate_act(acc[0][r], acc[2][r]);
+                o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+            }
+            if constexpr (F32) {
+                f32x4 a[4];
+                a[0] = frag(Af, kA1Size, 0, 8, 0, lane);
+                a[1] = frag(Af, kA1Size, 1, 8, 0, lane);
+                gemm_groups_dense([&](int it, int g) -> f32x4 { return (it == 1 && g == 7) ? lf32 : frag(Af, kA1Size, it, 8, g, lane); },
+                                  acc2, a, [&](int ks) -> float { return o[ks]; }, [](int) {});
+            } else {
+                const f16x8 lf = __builtin_bit_cast(f16x8, lf32);
                 f16x8 ah[4], al[4];
                 first_frags<4, 2, 0, 1, 2>(A2, lane, ah, al);
-                float o[32];
                 f16x8 oh[4], ol[4];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o[r] = gate_act(acc[0][r], acc[2][r]);
-                    o[16 + r] = gate_act(acc[1][r], acc[3][r]);
-                }
                 split8<0>(o, oh[0], ol[0]);
                 split8<8>(o, oh[1], ol[1]);
                 split8<16>(o, oh[2], ol[2]);
@@ -497,33 +518,33 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 gemm16_dense(
                     [&](int comp, int it, int s) -> f16x8 { return (comp == 1 && it == 1 && s == 3) ? lf : frag16<4, 2>(A2, comp, it, s, lane); },
                     acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; }, [](int) {});
-                {
-                    const int so = out_soff(0);
-                    const int oo = toff(row);
-                    const bool shared = u + ((dn + 31) >> 5) >= u_end;      // units the right neighbour reads in layer 1: write-through
-                    if (valid) {
-                        if (shared) {
+            }
+            {
+                const int so = out_soff(0);
+                const int oo = toff(row);
+                const bool shared = u + ((dn + 31) >> 5) >= u_end;      // units the right neighbour reads in layer 1: write-through
+                if (valid) {
+                    if (shared) {
 #pragma unroll
-                            for (int g = 0; g < 8; ++g) {
-                                const int it = g >> 2, q = g & 3;
-                                const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ring_rs, oo + g * 1024, so, kAuxWriteThrough);
-                            }
-                        } else {
+                        for (int g = 0; g < 8; ++g) {
+                            const int it = g >> 2, q = g & 3;
+                            const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ring_rs, oo + g * 1024, so, kAuxWriteThrough);
+                        }
+                    } else {
 #pragma unroll
-                            for (int g = 0; g < 8; ++g) {
-                                const int it = g >> 2, q = g & 3;
-                                const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ring_rs, oo + g * 1024, so, PWV_PERSIST_STORE_AUX);
-                            }
+                        for (int g = 0; g < 8; ++g) {
+                            const int it = g >> 2, q = g & 3;
+                            const f32x4 v = {acc2[it][q * 4], acc2[it][q * 4 + 1], acc2[it][q * 4 + 2], acc2[it][q * 4 + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ring_rs, oo + g * 1024, so, PWV_PERSIST_STORE_AUX);
                         }
                     }
                 }
-                prev_addr = kDoneB + (u - u_begin);
-                prev_j = 0;
-                j = j2;
-                u = u2;
             }
+            prev_addr = kDoneB + (u - u_begin);
+            prev_j = 0;
+            j = j2;
+            u = u2;
         }
     }
     if (u >= 0) {
@@ -940,7 +961,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
         }
         p.x_limit = a->x_limit;
         p.range_flag = a->range_flag;
-        for (int g = 0; g < a->G; ++g) p.fold0[g] = (a->precision == PWV_PREC_F16X3) ? a->first_fold[g] : nullptr;
+        for (int g = 0; g < a->G; ++g) p.fold0[g] = a->first_fold[g];
         for (int g = 1; g < a->G; ++g)
             PWV_CHECK_ARG((p.fold0[g] == nullptr) == (p.fold0[0] == nullptr), "pwv_wavenet_stack_persist_f32: first_fold must be set for all nets or for none");
     }

@@ -77,10 +77,11 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
     assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 1)      # it really was persistent
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('n,t,L,G,cond', [(1, 16000, 10, 2, 'frames'), (3, 2400, 6, 1, 'frames'), (2, 4000, 5, 2, 'none'), (1, 1234, 3, 2, 'samples')])
-def test_folded_layer0_is_the_same_function_on_every_path(gpu, persist_knobs, n, t, L, G, cond):
-    """Split-fp16 path, scalar-input nets: layer 0's filter|gate convolution folded onto the four scalars it is a function
-    of (pwv_pack_first_fold_f16x3; the default) -- the persistent launch and the per-layer FIRST kernels (also with a
+def test_folded_layer0_is_the_same_function_on_every_path(gpu, persist_knobs, n, t, L, G, cond, precision):
+    """Scalar-input nets (split-fp16 and fp32 paths): layer 0's filter|gate convolution folded onto the four scalars it is a function
+    of (pwv_pack_first_fold_f16x3 / _f32; the default) -- the persistent launch and the per-layer FIRST kernels (also with a
     per-sample condition) perform the same operations, so they agree bit for bit, and the folded result stays within the
     path's tolerance of the unfolded one (h[t] = x[t-1] w0 + x[t] w1 evaluated first, modules.py:179-180)."""
     import torch
@@ -94,22 +95,22 @@ def test_folded_layer0_is_the_same_function_on_every_path(gpu, persist_knobs, n,
         c = (torch.rand((n, t, 80), generator=g) * 2 - 1).to(gpu)
     else:
         c = None
-    engine.run_nets(nets, x, c, precision='f16x3')  # creates the variables
+    engine.run_nets(nets, x, c, precision=precision)  # creates the variables
     for name in list(store.vars):
         if store.vars[name].dim() == 1:
             store.vars[name].normal_(0, 0.1)
     store.version += 1
     engine.FOLD_FIRST = True
-    engine.run_nets(nets, x, c, precision='f16x3')       # (the plans are made here, with the folded fragments)
+    engine.run_nets(nets, x, c, precision=precision)       # (the plans are made here, with the folded fragments)
     res = {}
     for fold in (False, True):
         for persist in (False, True):
             engine.FOLD_FIRST, engine.PERSIST = fold, persist
-            res[fold, persist] = [o.clone() for o in engine.run_nets(nets, x, c, precision='f16x3')]
+            res[fold, persist] = [o.clone() for o in engine.run_nets(nets, x, c, precision=precision)]
             torch.cuda.synchronize()
             assert engine.persist_status() == 0
     mode = 'none' if c is None else ('frames' if cond == 'frames' else 'samples')
-    assert all(engine.get_plan(net, mode, engine.PRECISIONS['f16x3']).first_fold is not None for net in nets)
+    assert all(engine.get_plan(net, mode, engine.PRECISIONS[precision]).first_fold is not None for net in nets)
     for k in range(G):
         assert torch.equal(res[False, False][k], res[False, True][k]) and torch.equal(res[True, False][k], res[True, True][k])
         a, b = res[False, False][k], res[True, False][k]
