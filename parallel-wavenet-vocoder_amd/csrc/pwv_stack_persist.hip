@@ -415,11 +415,24 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const int dn = dil_of(1 < L ? 1 : 0);
         typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
         const lds_f4_t cfb = (lds_f4_t)(lds + kCfF + 4 * h);
+        // the folded fragments and the dense tail are the same for every unit: registers for the whole loop
+        f16x8 fh[4], fl[4];      // split-fp16: [hi | lo][4 row tiles][64 lanes] f16x8
+        f32x4 ff[4];             // fp32: [4 row tiles][64 lanes] {k = h, k = 2 + h, 0, 0}
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if constexpr (F32) {
+                ff[it] = *reinterpret_cast<const f32x4*>(F0 + it * 1024 + lane * 16);
+            } else {
+                fh[it] = *reinterpret_cast<const f16x8*>(F0 + it * 1024 + lane * 16);
+                fl[it] = *reinterpret_cast<const f16x8*>(F0 + (4 + it) * 1024 + lane * 16);
+            }
+        }
+        const f32x4 lf32 = *reinterpret_cast<const f32x4*>(lastfrag);      // (16 bytes either way)
         while (u >= 0 && j == 0) {
             int row, rc, nn, t;
             bool valid;
             unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
-            // the four scalars (zero left of the utterance start), the P row, the folded fragments, the dense tail
+            // the four scalars (zero left of the utterance start) and the P row
             const float* x1 = p.x_first;
             const bool has_prev = t >= d;
             const float x0 = x1[rc];
@@ -440,18 +453,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                     }
             }
-            f16x8 fh[4], fl[4];      // split-fp16: [hi | lo][4 row tiles][64 lanes] f16x8
-            f32x4 ff[4];             // fp32: [4 row tiles][64 lanes] {k = h, k = 2 + h, 0, 0}
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if constexpr (F32) {
-                    ff[it] = *reinterpret_cast<const f32x4*>(F0 + it * 1024 + lane * 16);
-                } else {
-                    fh[it] = *reinterpret_cast<const f16x8*>(F0 + it * 1024 + lane * 16);
-                    fl[it] = *reinterpret_cast<const f16x8*>(F0 + (4 + it) * 1024 + lane * 16);
-                }
-            }
-            const f32x4 lf32 = *reinterpret_cast<const f32x4*>(lastfrag);      // (16 bytes either way)
             int j2 = 0;
             const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);
             // drain (the loads above, the previous unit's stores), publish that unit, claim the task after the next
