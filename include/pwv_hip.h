@@ -228,7 +228,7 @@ typedef struct pwv_layer_args {
      * traffic per sample for this layer and no front launch.  x_first is [N*T] float32 (the flow's input). */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];   /* [2,1,64] each */
-    /* optional, PWV_PREC_F16X3 / PWV_PREC_F32 with x_first: pwv_pack_first_fold_f16x3's / _f32's output per net (all nets or none).  Layer 0's
+    /* optional, with x_first: pwv_pack_first_fold_f16x3's (PWV_PREC_F16X3, PWV_PREC_F16) / _f32's (PWV_PREC_F32) output per net (all or none).  Layer 0's
      * filter|gate convolution then runs on the four scalars x[t-d-1], x[t-d], x[t-1], x[t] themselves -- one MFMA k-step
      * instead of eight: the same function (h[t] is linear in x[t-1], x[t]), rounded differently: within the path's
      * tolerance of the unfolded form, not bit-identical to it.  pwv_persist_args.first_fold does exactly the same. */

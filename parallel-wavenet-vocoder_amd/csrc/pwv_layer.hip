@@ -761,7 +761,7 @@ int pwv_wavenet_layer_f32(const pwv_layer_args* a, pwv_stream_t stream) {
         lp.head_out[g] = a->head_out[g];
         PWV_CHECK_ARG(!a->x_first || a->causal_filter[g], "pwv_wavenet_layer_f32: x_first needs causal_filter for net %d", g);
         lp.cfilt[g] = a->causal_filter[g];
-        lp.fold0[g] = (a->x_first && a->precision != PWV_PREC_F16) ? a->first_fold[g] : nullptr;
+        lp.fold0[g] = a->x_first ? a->first_fold[g] : nullptr;
         PWV_CHECK_ARG((lp.fold0[g] == nullptr) == (lp.fold0[0] == nullptr), "pwv_wavenet_layer_f32: first_fold must be set for all nets or for none");
         PWV_CHECK_ARG(a->x_in[g] != a->x_out[g], "pwv_wavenet_layer_f32: in-place layers are not supported (x[t-d] halo)");
         lp.x_in[g] = a->x_in[g];

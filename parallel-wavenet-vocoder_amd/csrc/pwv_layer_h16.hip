@@ -139,8 +139,11 @@ __device__ __forceinline__ void stage_head_h16(f16x8* hl, float* fl, const float
 // iaf_front_h16_kernel (fp32 fma, then ONE rounding to fp16): no front launch, no [rows, 64] fp16 buffer written and read twice.
 // HEAD: the LAST layer with the head behind it -- the gated output's fp16 fragments are the B operand of the skip GEMM, exactly
 // the bits head_h16_kernel would have read back from HBM.  103 KB of LDS with a per-sample condition: one 8-wave workgroup per CU.
-template <bool COND, bool GATED, bool FIRST = false, bool HEAD = false>
+// FOLD (with FIRST): layer 0's filter|gate convolution on the four scalars themselves (the `hi` fragments of
+//   pwv_pack_first_fold_f16x3; see layer_f16x3_kernel): one MFMA k-step instead of eight.
+template <bool COND, bool GATED, bool FIRST = false, bool HEAD = false, bool FOLD = false>
 __global__ __launch_bounds__(HEAD ? 512 : 256, HEAD ? 1 : PWV_H16_MINWAVES) void layer_h16_kernel(const LayerParams p) {
+    static_assert(!FOLD || FIRST, "FOLD: layer 0 of a scalar-input net only");
     static_assert(!HEAD || GATED, "HEAD: the last layer only");
     constexpr int WAVES = HEAD ? 8 : 4;
     constexpr int kUnits = COND ? kH_END : kH_AC;
@@ -194,6 +197,8 @@ __global__ __launch_bounds__(HEAD ? 512 : 256, HEAD ? 1 : PWV_H16_MINWAVES) void
         const _Float16* xr = xin + xoff(rc, h, 64);
         const _Float16* xp = xin + xoff(has_prev ? rc - p.dilation : rc, h, 64);
         f16x8 b[8];          // k-steps 0..3 = x[t-d], 4..7 = x[t]: straight from HBM into the B operand
+        f16x8 fold_b = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)fold_b;
         if constexpr (FIRST) {
             // the four scalars the two rows are functions of (zero left of the utterance start), then per k-step the lane's eight
             // channels 16s + 8(q>>2) + 4h + (q&3): round(x[t-1] w0), fma(x[t], w1, .), one rounding to fp16 (iaf_front_h16_kernel)
@@ -211,8 +216,13 @@ __global__ __launch_bounds__(HEAD ? 512 : 256, HEAD ? 1 : PWV_H16_MINWAVES) void
                     vb[q] = fmaf(xd0, cf[64 + c], xd1 * cf[c]);
                 }
                 const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                b[4 + s] = to_h8<0>(vc);
-                b[s] = has_prev ? to_h8<0>(vb) : zero;
+                b[4 + s] = to_h8<0>(vc);      // (x[t]: the residual add needs it in every form)
+                b[s] = (has_prev && !FOLD) ? to_h8<0>(vb) : zero;
+            }
+            if constexpr (FOLD) {             // k = 0..3 of ONE k-step, lanes of the lower half: x[t-d-1], x[t-d], x[t-1], x[t]
+                const float sc[4] = {xd1, xd0, xm1, x0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fold_b[q] = (_Float16)(h == 0 ? sc[q] : 0.f);
             }
         } else {
 #pragma unroll
@@ -243,7 +253,13 @@ __global__ __launch_bounds__(HEAD ? 512 : 256, HEAD ? 1 : PWV_H16_MINWAVES) void
                 }
         }
         if constexpr (COND) gemm_h<5, 4>(&lds[kH_AC], lane, acc, [&](int s) -> f16x8 { return cb[s]; });
-        gemm_h<8, 4>(&lds[kH_A1], lane, acc, [&](int s) -> f16x8 { return b[s]; });
+        if constexpr (FOLD) {
+            const f16x8* F0 = reinterpret_cast<const f16x8*>(p.fold0[net]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F0[it * 64 + lane], fold_b, acc[it], 0, 0, 0);
+        } else {
+            gemm_h<8, 4>(&lds[kH_A1], lane, acc, [&](int s) -> f16x8 { return b[s]; });
+        }
 
         float o[32];
 #pragma unroll
@@ -392,9 +408,9 @@ __global__ void cond_to_h16_kernel(const float* __restrict__ cond, _Float16* __r
     }
 }
 
-template <bool COND, bool GATED, bool FIRST, bool HEAD>
+template <bool COND, bool GATED, bool FIRST, bool HEAD, bool FOLD = false>
 static void launch_h16(const LayerParams& lp, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((layer_h16_kernel<COND, GATED, FIRST, HEAD>), dim3(grid), dim3(HEAD ? 512 : 256), 0, s, lp);
+    hipLaunchKernelGGL((layer_h16_kernel<COND, GATED, FIRST, HEAD, FOLD>), dim3(grid), dim3(HEAD ? 512 : 256), 0, s, lp);
 }
 
 int launch_layer_h16(const LayerParams& lp, bool cond, bool gated, int per_net, hipStream_t s) {
@@ -404,6 +420,9 @@ int launch_layer_h16(const LayerParams& lp, bool cond, bool gated, int per_net, 
     if (head) {
         if (cond) launch_h16<true, true, false, true>(lp, grid, s);
         else launch_h16<false, true, false, true>(lp, grid, s);
+    } else if (first && lp.fold0[0]) {
+        if (cond) { if (gated) launch_h16<true, true, true, false, true>(lp, grid, s); else launch_h16<true, false, true, false, true>(lp, grid, s); }
+        else { if (gated) launch_h16<false, true, true, false, true>(lp, grid, s); else launch_h16<false, false, true, false, true>(lp, grid, s); }
     } else if (first) {
         if (cond) { if (gated) launch_h16<true, true, true, false>(lp, grid, s); else launch_h16<true, false, true, false>(lp, grid, s); }
         else { if (gated) launch_h16<false, true, true, false>(lp, grid, s); else launch_h16<false, false, true, false>(lp, grid, s); }

@@ -420,17 +420,19 @@ class NetPlan:
         # of (first_fold in the C ABI's argument structs); on the split-fp16 path the scalars themselves are then fp16 operands,
         # hence the extra bound on them
         self.first_fold = None
-        if (precision in (_lib.PREC_F16X3, _lib.PREC_F32) and FOLD_FIRST and self.f16x3_ok and net.in_channels == 1 and net.filter_width == 2
+        if (FOLD_FIRST and self.f16x3_ok and net.in_channels == 1 and net.filter_width == 2
                 and net.residual_channels == 64 and net.dilation_channels == 64 and self.causal_bias is None):
             v0 = self._lv(0)
             ff = torch.zeros((_lib.FIRST_FOLD_FLOATS,), dtype=torch.float32, device=dev)
-            pack = lib.pwv_pack_first_fold_f16x3 if precision == _lib.PREC_F16X3 else lib.pwv_pack_first_fold_f32
+            # (the fp16 storage mode reads the `hi` fragments of the split-fp16 layout, as it does for every other weight)
+            pack = lib.pwv_pack_first_fold_f32 if precision == _lib.PREC_F32 else lib.pwv_pack_first_fold_f16x3
             check(pack(_ptr(self.causal_filter), _ptr(v0['filter']), _ptr(v0['gate']), _ptr(ff), s), 'pwv_pack_first_fold')
             if precision == _lib.PREC_F32:
                 self.first_fold = ff
             elif bool(torch.isfinite(ff.view(torch.float16).float()).all()):
                 self.first_fold = ff
-                self.x_limit = min(self.x_limit, F16_LIMIT)
+                if precision == _lib.PREC_F16X3:
+                    self.x_limit = min(self.x_limit, F16_LIMIT)
 
     def _range_analysis(self, net, L, use_skip, cond_mode):
         """Bound every operand the split-fp16 kernels convert to fp16 (weights after the exp2 scale folding; the residual

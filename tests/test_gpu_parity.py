@@ -380,20 +380,19 @@ def test_fused_first_layer_and_fused_head_are_bit_identical(gpu, method, precisi
     weights = O.init_weights(cfg, seed=21)
     mel, z = O.synthetic_inputs(3, 80 * 7, cfg)
     monkeypatch.setattr(engine, 'FUSE_FIRST', True)
-    # (the default of the split-fp16 and fp32 paths goes one step further and folds layer 0's convolution onto the scalars: another
+    # (the default of all three arithmetics goes one step further and folds layer 0's convolution onto the scalars: another
     # evaluation order, checked against this one below and in tests/test_gpu_persist.py)
     monkeypatch.setattr(engine, 'FOLD_FIRST', False)
     a = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     monkeypatch.setattr(engine, 'FUSE_FIRST', False)
     b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     assert np.array_equal(a, b)
-    if precision in ('f16x3', 'f32'):
-        monkeypatch.setattr(engine, 'FUSE_FIRST', True)
-        monkeypatch.setattr(engine, 'FOLD_FIRST', True)
-        f = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
-        assert not np.array_equal(a, f) and np.abs(a - f).max() <= 1e-5
-        assert np.abs(f - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
-        monkeypatch.setattr(engine, 'FOLD_FIRST', False)
+    monkeypatch.setattr(engine, 'FUSE_FIRST', True)
+    monkeypatch.setattr(engine, 'FOLD_FIRST', True)
+    f = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
+    assert not np.array_equal(a, f) and np.abs(a - f).max() <= (5e-3 if precision == 'f16' else 1e-5)
+    assert np.abs(f - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= (5e-3 if precision == 'f16' else TOL_F32)
+    monkeypatch.setattr(engine, 'FOLD_FIRST', False)
     # ... and the same for the head fused behind the last layer (the gated output stays in registers)
     monkeypatch.setattr(engine, 'FUSE_HEAD', False)
     c = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
