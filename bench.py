@@ -181,8 +181,12 @@ def main():
     # max-over-ranks / rank-0 JSON control flow with a no-op step, over gloo on CPU.
     # PWV_BENCH_DRYRUN_ONE_GPU=1 (test hook, tests/test_gpu_unfused_and_e2e.py): the real step, but all ranks share GPU 0 and
     # rendezvous over gloo, to exercise the multi-rank path on a 1-GPU box.
+    # PWV_BENCH_FORCE_DIST=1 (de-risks the driver's multi-GPU run on a 1-GPU box): `--gpus 1` initialises the `nccl` backend
+    # (= RCCL) at world size 1 and takes EVERY distributed branch below -- barriers, the MAX all-reduce of the elapsed time on
+    # a device tensor, the give-up vote, generate_sharded / generate_time_sharded_ranks over nccl scatter / gather.
     control = os.environ.get('PWV_BENCH_DRYRUN') == 'control'
     dryrun = control or os.environ.get('PWV_BENCH_DRYRUN_ONE_GPU') == '1'
+    force_dist = os.environ.get('PWV_BENCH_FORCE_DIST') == '1'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     import torch
@@ -201,7 +205,15 @@ def main():
         dev = torch.device('cuda', dev_index)
     dist = None
     backend = None
-    if world > 1:
+    if world > 1 or force_dist:
+        if world == 1 and 'MASTER_PORT' not in os.environ:      # (no launcher: rendezvous with ourselves)
+            import socket
+            sk = socket.socket()
+            sk.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+            sk.close()
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         # keep stdout to the one JSON line: RCCL's version banner (NCCL_DEBUG=VERSION/INFO) would land there
         if os.environ.get('NCCL_DEBUG', '').upper() in ('VERSION', 'INFO', ''):
             os.environ['NCCL_DEBUG'] = 'WARN'
@@ -260,7 +272,7 @@ def main():
         store = VariableStore(device=dev, seed=2)
         model0 = IAFVocoder(batch_size=utts, length=length, store=store, precision=args.precision)
         model0.noise_seed = 1 + (0 if time_shard else rank)
-        model0(None, mel, is_training=False)            # creates the variables
+        model0(None, mel, is_training=False, verify=False)            # creates the variables
         for name in list(store.vars):
             if store.vars[name].dim() == 1:
                 store.vars[name].normal_(0, 0.1, generator=None)
@@ -272,8 +284,8 @@ def main():
             model = model0 if precision == args.precision else IAFVocoder(batch_size=utts, length=length, store=store, precision=precision)
             model.noise_seed = 1 + rank
 
-            def eager_step():
-                return model(None, mel, is_training=False)
+            def eager_step():      # enqueue-only, like the C ABI: the timed loop must not synchronise; model0.verify() follows it
+                return model(None, mel, is_training=False, verify=False)
 
             if args.no_graph:
                 return eager_step, eager_step, False
@@ -284,7 +296,7 @@ def main():
                 graphed = GraphedVocoder(model)
                 # self-check (untimed): a replay must reproduce the host-enqueued forward bit for bit on the same noise
                 zc = engine.logistic_noise_op((utts, length, 1), dev, seed=12345)
-                want = model(None, mel, is_training=False, z=zc).clone()
+                want = model(None, mel, is_training=False, z=zc, verify=False).clone()
                 got = graphed(mel, z=zc)
                 torch.cuda.synchronize()
                 if not torch.equal(want, got):
@@ -353,19 +365,6 @@ def main():
                 raise failed[0] if failed else _lib.PwvPersistError('a persistent launch gave up on another rank, twice')
             sys.stderr.write('%s\nre-timing with per-layer launches\n' % (failed[0] if failed else 'a persistent launch gave up on another rank'))
 
-    def checked_forward(call):
-        """one untimed forward, rerun once if a persistent launch (its own or an earlier one) gave up"""
-        for attempt in (0, 1):
-            try:
-                y = call()
-                torch.cuda.synchronize()
-                engine.raise_if_persist_failed()
-                return y
-            except _lib.PwvPersistError as e:
-                if attempt:
-                    raise
-                sys.stderr.write('%s\nrerunning on per-layer launches\n' % e)
-
     (step, eager_step, graphed), elapsed, out = timed_verified(args.precision, args.warmup, args.steps)
     assert torch.isfinite(out).all(), 'non-finite output'
 
@@ -392,7 +391,7 @@ def main():
                 win = (m.shape[1] - 1) * hop
                 net = model0 if win == length else IAFVocoder(batch_size=m.shape[0], length=win, store=store, precision=args.precision)
                 zw = engine.logistic_noise_window(m.shape[0], job_length, t0, win, dev, 4242)
-                return checked_forward(lambda: net(None, m.to(dev), is_training=False, z=zw)).to(coll_dev)
+                return net(None, m.to(dev), is_training=False, z=zw).to(coll_dev)      # (a verified call: rerun inside if a sticky word is raised)
         wav = generate_time_sharded_ranks(fwd, full_mel, n_mels, job_length, hop, time_shard['halo'], coll_dev)
         if rank == 0:
             assert tuple(wav.shape) == (utts, job_length, 1) and bool(torch.isfinite(wav).all())
@@ -408,7 +407,7 @@ def main():
         else:
             def fwd(m, zz):
                 net = model0 if m.shape[0] == utts else IAFVocoder(batch_size=m.shape[0], length=length, store=store, precision=args.precision)
-                return checked_forward(lambda: net(None, m.to(dev), is_training=False, z=zz)).to(coll_dev)
+                return net(None, m.to(dev), is_training=False, z=zz).to(coll_dev)      # (a verified call)
         wav = generate_sharded(fwd, full_mel, (t_mel, n_mels), length, coll_dev)
         if rank == 0:
             assert tuple(wav.shape) == (total, length, 1) and bool(torch.isfinite(wav).all())

@@ -330,32 +330,10 @@ typedef struct pwv_stack_args {
     int separate_head;                            /* 1: never fuse the head into the last layer's launch */
     float x_limit;                                /* forwarded to layer 0 (pwv_layer_args.x_limit / range_flag) */
     int* range_flag;
-    const float* x_first_chain1;                  /* two-stream mode: the second chain reads its own copy of the flow input
-                                                   * (pwv_iaf_affine_sync_f32); NULL = both nets read x_first */
     const float* first_fold[PWV_MAX_NETS];        /* optional, forwarded to layer 0 (pwv_layer_args.first_fold) */
 } pwv_stack_args;
 
 int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* streams);
-
-/* ---------------------------------------------------------------------------------------
- * The IAF affine out = z * s + b (modules.py:59) for a chain that does NOT return to a common stream between two
- * flows.  The scalar and the shifter net of a flow run as two launch chains on two streams (pwv_wavenet_stack_f32); the
- * next flow's input needs BOTH heads.  Instead of a queue-level join + fork (measured: ~50 us per flow boundary on a
- * two-queue HIP graph) each chain evaluates the affine for itself, into its own copy of x, and meets the other chain
- * through two words in device memory:
- *   the launch first publishes *my_flag = 1 (its own chain's head is complete: it sits behind it on the stream), then
- *   waits for *other_flag != 0 (one lane per workgroup polls, bounded), acquires, and computes.
- * `skew_us` > 0 keeps the launch waiting that much longer once the other flag is up: two chains released at the same instant
- * run in lockstep and meet their launch gaps and tails together; a few microseconds of skew keep them out of phase.
- * Both flags NULL: a plain affine.  `s` / `b` are read with stride sb_stride.  The grid is small (<= 32 workgroups) so that
- * the waiting launch never keeps the other chain's kernels off the chip.  The caller zeroes the flags before every forward.
- *   pwv_sync_status(&p)   process-wide sticky int32 in pinned host memory: != 0 once a wait ran into its bound (50 ms: the
- *                         two chains were not running concurrently, e.g. under a profiler that serialises kernels); the
- *                         outputs of that forward are invalid and the caller falls back to stream-level joins.
- * ------------------------------------------------------------------------------------- */
-int pwv_iaf_affine_sync_f32(const float* z, const float* s, const float* b, int sb_stride, float* out, int64_t n,
-                            int* my_flag, const int* other_flag, int skew_us, pwv_stream_t stream);
-int pwv_sync_status(int** status);
 
 /* ---------------------------------------------------------------------------------------
  * Normalisers (modules.normalize, modules.py:263-284) and the elementwise ops of the un-fused WaveNet path.

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
     'pwv_linear_split_f32', 'pwv_pack_first_fold_f16x3', 'pwv_pack_first_fold_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_range_check_f32', 'pwv_range_stats_f32',
-    'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32', 'pwv_iaf_affine_sync_f32', 'pwv_sync_status',
+    'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32',
     'pwv_wav_to_mel_db_f32', 'pwv_pack_proj_f32', 'pwv_instance_norm_workspace_bytes', 'pwv_instance_norm_f32', 'pwv_channel_affine_f32', 'pwv_add_f32', 'pwv_gate_f32',
 )
 
@@ -121,7 +121,6 @@ class StackArgs(Structure):
         ('separate_head', c_int),
         ('x_limit', ctypes.c_float),
         ('range_flag', c_void_p),
-        ('x_first_chain1', c_void_p),
         ('first_fold', c_void_p * PWV_MAX_NETS),
     ]
 
@@ -223,8 +222,6 @@ def _declare(lib):
     lib.pwv_persist_workspace_bytes.restype = c_size_t
     lib.pwv_persist_workspace_bytes.argtypes = [POINTER(PersistArgs)]
     lib.pwv_persist_status.argtypes = [POINTER(c_void_p)]
-    lib.pwv_sync_status.argtypes = [POINTER(c_void_p)]
-    lib.pwv_iaf_affine_sync_f32.argtypes = [f32p, f32p, f32p, c_int, f32p, c_int64, c_void_p, c_void_p, c_int, c_void_p]
     lib.pwv_wavenet_stack_persist_f32.argtypes = [POINTER(PersistArgs), c_void_p]
     lib.pwv_range_stats_f32.argtypes = [f32p] * 8 + [c_int, f32p, c_void_p]
     lib.pwv_range_flag.argtypes = [POINTER(c_void_p)]

@@ -938,7 +938,7 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* a, pwv_stream_t const* streams) 
                 la.head_q = a->Q;
             }
             if (j == 0 && a->x_first) {
-                la.x_first = (two && grp == 1 && a->x_first_chain1) ? a->x_first_chain1 : a->x_first;
+                la.x_first = a->x_first;
                 la.x_limit = a->x_limit;
                 la.range_flag = a->range_flag;
                 for (int i = 0; i < per_group; ++i) {

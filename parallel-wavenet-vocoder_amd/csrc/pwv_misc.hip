@@ -393,34 +393,6 @@ __global__ void range_check_kernel(const float* __restrict__ x, long long n, flo
     if (i < n && !(fabsf(x[i]) <= limit)) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// IAF affine with a two-chain handshake (include/pwv_hip.h, pwv_iaf_affine_sync_f32): publish, wait (bounded), acquire, compute
-constexpr long long kSyncTimeoutTicks = 5000000;      // 50 ms of the chip-wide 100 MHz clock
-__global__ __launch_bounds__(256) void iaf_affine_sync_kernel(const float* __restrict__ z, const float* s, const float* b, int sb_stride,
-                                                              float* __restrict__ out, long long n, int* my_flag, const int* other_flag,
-                                                              int* status, int skew_ticks) {
-    if (my_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(my_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (other_flag) {
-        if (threadIdx.x == 0) {
-            const long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(other_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                if (__builtin_amdgcn_s_memrealtime() - t0 > kSyncTimeoutTicks) {
-                    __hip_atomic_store(status, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(16);
-            }
-            if (skew_ticks > 0) {      // keep this chain a little behind the other one (see pwv_hip.h)
-                const long long t1 = __builtin_amdgcn_s_memrealtime();
-                while (__builtin_amdgcn_s_memrealtime() - t1 < skew_ticks) __builtin_amdgcn_s_sleep(8);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the other chain's output
-        }
-        __syncthreads();
-    }
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        out[i] = fmaf(z[i], s[i * sb_stride], b[i * sb_stride]);      // (the operation of iaf_front_kernel: bit-identical)
-}
-
 static inline unsigned blocks_for(long long total, int threads) { return (unsigned)((total + threads - 1) / threads); }
 
 }  // namespace pwv
@@ -582,33 +554,6 @@ int pwv_iaf_front_f32(const float* z, const float* s, const float* b, int sb_str
                   "pwv_iaf_front_f32: filter width %d / %d channels not supported (W <= %d, W*R <= %d)", W, R, kFrontMaxTaps, kFrontMaxFilt);
     PWV_CHECK_ARG(W <= kFrontMaxTaps, "pwv_iaf_front_f32: W must be <= %d", kFrontMaxTaps);
     hipLaunchKernelGGL(iaf_front_kernel, dim3(blocks_for((long long)N * T, 256), G > 0 ? G : 1), dim3(256), 0, (hipStream_t)stream, p);
-    PWV_CHECK_HIP(hipGetLastError());
-    return PWV_OK;
-}
-
-int pwv_sync_status(int** status) {
-    static int* g_status = nullptr;      // process lifetime; pinned + mapped: one pointer valid on host and device
-    PWV_CHECK_ARG(status, "pwv_sync_status: NULL argument");
-    if (!g_status) {
-        PWV_CHECK_HIP(hipHostMalloc((void**)&g_status, sizeof(int), hipHostMallocMapped | hipHostMallocPortable));
-        *g_status = 0;
-    }
-    *status = g_status;
-    return PWV_OK;
-}
-
-int pwv_iaf_affine_sync_f32(const float* z, const float* s, const float* b, int sb_stride, float* out, int64_t n,
-                            int* my_flag, const int* other_flag, int skew_us, pwv_stream_t stream) {
-    PWV_CHECK_ARG(z && s && b && out && n >= 0 && sb_stride >= 1 && skew_us >= 0 && skew_us <= 1000, "pwv_iaf_affine_sync_f32: bad arguments");
-    if (n == 0) return PWV_OK;
-    int* status = nullptr;
-    const int rc = pwv_sync_status(&status);
-    if (rc != PWV_OK) return rc;
-    // a small grid: the launch may sit on the chip waiting for the other chain, whose kernels need whole CUs
-    unsigned blocks = blocks_for(n, 256 * 4);
-    if (blocks > 32) blocks = 32;
-    hipLaunchKernelGGL(iaf_affine_sync_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, s, b, sb_stride, out, (long long)n,
-                       my_flag, other_flag, status, skew_us * 100);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

@@ -40,43 +40,35 @@ DEFAULT_PRECISION = os.environ.get('PWV_PRECISION', 'f16x3')
 # launch stream and appends (tag, start_event, end_event): bench.py's live kernel timing.
 EVENT_LOG = None
 
-# The scalar and shifter nets of a flow are independent dependency chains.  With TWO_STREAMS each
-# chain gets its own HIP stream and half of the CUs per launch (G=1), so the two chains drift out
-# of phase and one chain's launch gap / cold start / tail is covered by the other's bulk
-# (measured: 48 vs 55 us per layer pair at 160000 samples).  Otherwise both nets share one launch.
+# Environment knobs (five, all read once at import): PWV_PRECISION (above), PWV_PERSIST, PWV_TWO_STREAMS, PWV_FOLD_FIRST,
+# PWV_ASYNC.  Everything else below is a module attribute that tests / tools set directly.
+#
+# The scalar and shifter nets of a flow are independent dependency chains.  On the per-layer path (PWV_PERSIST=0, or a shape
+# the persistent launch does not cover) TWO_STREAMS gives each chain its own HIP stream and half of the CUs per launch
+# (G = 1), so one chain's launch gap / tail is covered by the other's bulk; otherwise both nets share one G = 2 launch.
 TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
-# PWV_HOIST_P=0: every flow computes its own frame-rate projections at its start (A/B knob; default: one GEMM for all
-# nets of the forward before the first flow, see project_all)
-HOIST_P = os.environ.get('PWV_HOIST_P', '1') != '0'
-# PWV_FUSE_FIRST=0: materialise the causal layer with the front kernel even where layer 0 could rebuild it (A/B knob)
-FUSE_FIRST = os.environ.get('PWV_FUSE_FIRST', '1') != '0'
-# PWV_FOLD_FIRST=0: layer 0 of the persistent launch runs its filter|gate GEMM on the rebuilt causal-layer rows (eight MFMA
-# k-steps) instead of on the four scalars they are a function of (one k-step); default: folded (split-fp16 path)
+# layer 0 rebuilds the causal layer from the flow's scalar input / the head runs behind the last layer (tests switch them
+# off to check the fused forms bit for bit against the separate launches)
+FUSE_FIRST = True
+FUSE_HEAD = True
+HOIST_P = True               # one projection GEMM per forward (project_all); False: every net projects for itself (cross-check in tests)
+# PWV_FOLD_FIRST=0: layer 0 runs its filter|gate GEMM on the rebuilt causal-layer rows (eight MFMA k-steps) instead of on the
+# four scalars they are a function of (one k-step); default: folded.  The only knob that changes bits.
 FOLD_FIRST = os.environ.get('PWV_FOLD_FIRST', '1') != '0'
-# PWV_FUSE_HEAD=0: keep the head a separate launch even where the last layer could run it (A/B knob)
-FUSE_HEAD = os.environ.get('PWV_FUSE_HEAD', '1') != '0'
-# The residual layers 1 .. L-2 of a stack as ONE persistent launch (csrc/pwv_stack_persist.hip, bit-identical results)
-# instead of one launch per layer.  PWV_PERSIST = 0 | 1 | auto (default).  Measured on MI355X under HIP-graph replay
-# (same box, alternating runs): headline C3 2.86 vs 3.02 ms per step, C2 1.57 vs 1.72 ms, C4 share 9.20 vs
-# 9.33 ms, C1 0.119 vs 0.148 ms, default model at 16000 samples 0.64 vs 0.80 ms, exact fp32 6.80 vs 6.94 ms.
-# 'auto' takes it wherever the library supports the shape (up to PERSIST_AUTO_MAX_ROWS rows per launch); '1' forces it.
+# The residual layers of a stack as ONE persistent launch (csrc/pwv_stack_persist.hip, bit-identical results) instead of one
+# launch per layer.  PWV_PERSIST = 0 | 1 | auto (default: wherever the library supports the shape; '1' forces it).
 _pm = os.environ.get('PWV_PERSIST', 'auto')
 PERSIST = {'0': False, '1': True}.get(_pm, 'auto')
-PERSIST_AUTO_MAX_ROWS = int(os.environ.get('PWV_PERSIST_AUTO_MAX_ROWS', str(1 << 30)))
-# short inputs: fewer workgroups rather than ranges below this many units (0 = the library's default, 4)
-PERSIST_MIN_UNITS = int(os.environ.get('PWV_PERSIST_MIN_UNITS', '0'))
-# longest run of layers in one persistent launch (a stack's residual layers are cut into equal runs that hand the ring on)
-PERSIST_MAX_LAYERS = int(os.environ.get('PWV_PERSIST_MAX_LAYERS', '32'))
-# The two nets of a flow run as two launch chains on two streams.  With CHAIN_FLOWS the chains stay on their streams ACROSS
-# the flows of a forward: each evaluates the IAF affine for itself and meets the other through two words of device memory
-# (pwv_iaf_affine_sync_f32) instead of a stream-level join + fork per flow (~50 us per flow boundary on a two-queue HIP graph).
-# PWV_CHAIN_FLOWS=0 restores the joins (A/B knob; also the fallback after a wait ran into its bound).
-CHAIN_FLOWS = os.environ.get('PWV_CHAIN_FLOWS', '0') != '0'
-CHAIN_SKEW_US = int(os.environ.get('PWV_CHAIN_SKEW_US', '0'))      # chain 1 leaves every flow boundary this much behind chain 0
-CHAIN_FORWARDS = 0        # forwards that took run_flow_chain (tests / tools look at it)
+PERSIST_AUTO_MAX_ROWS = 1 << 30
+PERSIST_MIN_UNITS = 0         # short inputs: fewer workgroups rather than ranges below this many units (0 = the library's default, 4)
+PERSIST_MAX_LAYERS = 32       # longest run of layers in one persistent launch (a stack is cut into equal runs that hand the ring on)
+# PWV_ASYNC=1: the reference-shaped calls (IAFVocoder / WaveNet / LinearIAFLayer __call__) only ENQUEUE, like the C ABI; the
+# caller then owns IAFVocoder.verify() / engine.verify_enqueued().  Default: a call returns only after its own launches
+# have completed and the library's sticky words (range guard, persistent give-up) are clean -- or it has rerun itself on
+# the path that is (per-layer launches / exact fp32).  bench.py, graph.py and generate() opt out per call (verify=False).
+ASYNC = os.environ.get('PWV_ASYNC', '0') == '1'
 _persist_status_addr = None
 _persist_ws = {}          # (device, stream) -> zeroed workspace of the persistent launches on that stream
-_sync_status_addr = None
 _side_streams = {}
 
 
@@ -103,25 +95,62 @@ def raise_if_persist_failed() -> None:
                                    'is used from now on, rerun the forward' % code)
 
 
-def sync_status() -> int:
-    """The library's sticky status word of the two-chain handshake (pinned host memory): 0, or != 0 once a wait for the other
-    chain ran into its bound (the chains were not running concurrently); that forward's outputs are invalid."""
-    global _sync_status_addr
-    if _sync_status_addr is None:
-        p = c_void_p()
-        check(_lib.lib().pwv_sync_status(ctypes.byref(p)), 'pwv_sync_status')
-        _sync_status_addr = p.value
-    return ctypes.c_int.from_address(_sync_status_addr).value
+_verify_depth = 0         # > 0 inside a reference-shaped call that owns the verification of everything it enqueues
 
 
-def raise_if_sync_failed() -> None:
-    global CHAIN_FLOWS
-    if _sync_status_addr is not None and sync_status() != 0:
-        ctypes.c_int.from_address(_sync_status_addr).value = 0
-        CHAIN_FLOWS = False
-        raise _lib.PwvPersistError('a launch chain waited for the other one in vain (the two streams were not running concurrently, '
-                                   'e.g. under a profiler that serialises kernels); the outputs are invalid -- stream-level joins are '
-                                   'used from now on, rerun the forward')
+def clear_persist_status() -> None:
+    if _persist_status_addr is not None:
+        ctypes.c_int.from_address(_persist_status_addr).value = 0
+
+
+def verify_enqueued(where: str = '') -> None:
+    """Wait for everything enqueued on this device and raise PwvPersistError / PwvRangeError if a launch that has completed
+    left one of the library's sticky words raised (what a caller of the enqueue-only forms owes before it reads a result)."""
+    torch.cuda.synchronize()
+    raise_if_persist_failed()
+    raise_if_range_flag(where)
+
+
+def verified_call(run, verify: Optional[bool] = None):
+    """The contract of the reference-shaped entry points (IAFVocoder / WaveNet / LinearIAFLayer / SharedIAFLayer __call__):
+    `run(precision_override)` enqueues the forward and returns its result tensor.  By default the OUTERMOST such call then waits
+    for its launches and looks at the two sticky words of the library (pinned host memory: no device -> host copy):
+      * a persistent stack launch gave up (its workgroups were not all resident): the engine has switched to per-layer launches
+        -- same arithmetic, same bits -- and the forward is rerun;
+      * an operand left the range of the split-fp16 arithmetic (the reference computes in fp32, models.py:81-82): the forward
+        is rerun with precision 'f32'.
+    So `pred = model(wav, mel, is_training=False); pred.cpu()` (generate.py:38,68) yields a correct result or an exception,
+    never inf from a silent fp16 overflow.  verify=False (or PWV_ASYNC=1, or a call under stream capture, or a call nested in
+    another reference-shaped call) only enqueues; the caller then owns verify_enqueued() / IAFVocoder.verify()."""
+    global _verify_depth, PERSIST
+    if verify is None:
+        verify = not ASYNC
+    if _verify_depth > 0 or not verify or torch.cuda.is_current_stream_capturing():
+        _verify_depth += 1
+        try:
+            return run(None)
+        finally:
+            _verify_depth -= 1
+    _verify_depth += 1
+    try:
+        out = run(None)
+        torch.cuda.current_stream().synchronize()
+        if persist_status() != 0:
+            clear_persist_status()
+            clear_range_flag()          # (whatever consumed the invalid rows may have raised it)
+            PERSIST = False
+            out = run(None)
+            torch.cuda.current_stream().synchronize()
+            raise_if_persist_failed()
+        if range_flag_raised():
+            clear_range_flag()
+            out = run('f32')
+            torch.cuda.current_stream().synchronize()
+            raise_if_persist_failed()
+            raise_if_range_flag("its rerun in precision 'f32'")
+        return out
+    finally:
+        _verify_depth -= 1
 
 
 def _persist_runs(L: int, first: int = 1) -> List[Tuple[int, int]]:
@@ -472,7 +501,7 @@ def get_plan(net, cond_mode: str, precision: int) -> NetPlan:
     key = (net.store.uid, net.full_scope, cond_mode, precision, tuple(int(d) for d in net.dilations),
            bool(net.use_skip_connection), bool(net.use_biases), net.in_channels, net.out_channels,
            net.condition_channels, net.filter_width, net.residual_channels, net.dilation_channels, net.skip_channels,
-           net.normalize or '')
+           net.normalize or '', bool(FOLD_FIRST))
     hit = _plan_cache.get(key)
     if hit is not None and hit[0] == net.store.version:
         return hit[1]
@@ -632,113 +661,6 @@ def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
     f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames, c)
     p_all = linear_op(f2d, w_all, b_all, relu=False, precision=precision or DEFAULT_PRECISION)
     cond.proj_bank = {id(p): p_all[:, o:o + p.proj_w.shape[1]] for p, o in zip(plans, offs)}
-
-
-def run_flow_chain(flow_nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None) -> Optional[torch.Tensor]:
-    """All flows of a forward (flow_nets = [(scalar net, shifter net), ...], models.py:34-70) with the two nets' launch chains
-    kept on their two streams from the first flow to the last: ONE fork, ONE join, and per flow boundary one small launch per
-    chain that meets the other chain through device memory and evaluates x' = x * s + b (modules.py:59) into the chain's own copy
-    of x.  Bit-identical to the per-flow form (same kernels, same operations).  Returns None when the forward is not of the shape
-    this covers (the caller then loops over the flows with run_nets): two-stream per-layer launches, scalar nets with the causal
-    layer rebuilt by layer 0, frame-rate or no condition with the hoisted projection bank, no skip accumulation."""
-    lib = _lib.lib()
-    prec = PRECISIONS[precision or DEFAULT_PRECISION]
-    if not (CHAIN_FLOWS and TWO_STREAMS and FUSE_FIRST and len(flow_nets) >= 2 and prec in (_lib.PREC_F16X3, _lib.PREC_F32)):
-        return None
-    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[2] == 1 and x.numel() > 0):
-        return None
-    x = _require_cuda_f32(x, 'input_batch')
-    n, t, _ = x.shape
-    if cond is None:
-        mode, hop, offset, frames_per_utt = 'none', 0, 0, 0
-    elif isinstance(cond, RepeatedCondition) and cond.length == t and cond.frames.shape[0] == n:
-        mode, hop, offset, frames_per_utt = 'frames', cond.hop, cond.offset, cond.frames.shape[1]
-    else:
-        return None
-    bank = getattr(cond, 'proj_bank', None) if mode == 'frames' else None
-    flows = []
-    for nets in flow_nets:
-        sc, sh = nets
-        for net in nets:
-            if not (getattr(net, 'fused_supported', None) and net.fused_supported(cond) and net.in_channels == 1 and net.out_channels == 1
-                    and net.filter_width == 2 and net.residual_channels == 64 and not net.use_skip_connection
-                    and (precision or DEFAULT_PRECISION) == (net.precision or precision or DEFAULT_PRECISION)):
-                return None
-            if mode == 'frames' and cond.frames.shape[2] != net.condition_channels:
-                return None
-        if not _same_structure(sc, sh) or len(sc.dilations) < 2 or _use_persist(2, n, t, sc.dilations):
-            return None
-        plans = [get_plan(net, mode, prec) for net in nets]
-        if any(p.causal_bias is not None for p in plans) or (prec == _lib.PREC_F16X3 and not all(p.f16x3_ok and p.x_limit > 0 for p in plans)):
-            return None
-        if mode == 'frames':
-            if bank is None or not all(id(p) in bank for p in plans):
-                return None
-            projs = [bank[id(p)] for p in plans]
-        else:
-            projs = [p.proj_b.reshape(1, -1) for p in plans]
-        flows.append((sc, plans, projs))
-    dev = x.device
-    rows = n * t
-    main = torch.cuda.current_stream()
-    side = _net_streams(dev)
-    # every buffer of the forward is allocated here and lives to the end of the function: nothing the chains still use can be
-    # handed out again by the allocator before the join below is on the main stream
-    bufs = [[torch.empty((lib.pwv_tile32_floats(rows, 64),), dtype=torch.float32, device=dev) for _ in range(2)] for _ in range(2)]
-    flags = torch.zeros((len(flows) * 2 * 32,), dtype=torch.int32, device=dev)      # one 128-byte line per (flow, chain)
-    keep = []
-    for g in range(2):
-        side[g].wait_stream(main)
-    streams = (c_void_p * 2)(side[0].cuda_stream, side[1].cuda_stream)
-    xg = [x, x]
-    for i, (net0, plans, projs) in enumerate(flows):
-        L = plans[0].n_layers
-        outs = [torch.empty((n, t, 1), dtype=torch.float32, device=dev) for _ in range(2)]
-        sa = StackArgs()
-        sa.G, sa.n_layers = 2, L
-        dil = (ctypes.c_int * L)(*[int(d) for d in net0.dilations])
-        sa.dilations = dil
-        for g in range(2):
-            sa.buf0[g], sa.buf1[g] = bufs[g][0].data_ptr(), bufs[g][1].data_ptr()
-            sa.packed_layers[g] = plans[g].packed_layers.data_ptr()
-            sa.proj[g] = projs[g].data_ptr()
-            sa.packed_head[g] = plans[g].packed_head.data_ptr()
-            sa.out[g] = outs[g].data_ptr()
-            sa.causal_filter[g] = plans[g].causal_filter.data_ptr()
-            if FOLD_FIRST and all(p.first_fold is not None for p in plans):
-                sa.first_fold[g] = plans[g].first_fold.data_ptr()
-        sa.packed_layer_stride = plans[0].layer_floats
-        sa.proj_row_stride = projs[0].stride(0) if mode == 'frames' else 128 * L
-        sa.Q, sa.N, sa.T = 1, n, t
-        sa.cond_hop, sa.cond_offset, sa.cond_frames = hop, offset, frames_per_utt
-        sa.precision = prec
-        sa.separate_head = 0 if FUSE_HEAD else 1
-        sa.x_first, sa.x_first_chain1 = _ptr(xg[0]), _ptr(xg[1])
-        sa.x_limit = min(p.x_limit for p in plans)
-        sa.range_flag = range_flag_ptr()
-        evs = []
-        if EVENT_LOG is not None and L > 1:      # bench.py's live kernel timing (see run_nets)
-            for c in range(2):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(side[c])
-                e1.record(side[c])
-                sa.ev_begin[c], sa.ev_end[c] = e0.cuda_event, e1.cuda_event
-                evs.append((e0, e1))
-        check(lib.pwv_wavenet_stack_f32(ctypes.byref(sa), streams), 'pwv_wavenet_stack_f32')
-        for e0, e1 in evs:
-            EVENT_LOG.append(('layer_residual', e0, e1, 1, L - 1))
-        newx = [torch.empty((n, t, 1), dtype=torch.float32, device=dev) for _ in range(2)]
-        for g in range(2):
-            mine, other = flags.data_ptr() + 4 * 32 * (2 * i + g), flags.data_ptr() + 4 * 32 * (2 * i + 1 - g)
-            check(lib.pwv_iaf_affine_sync_f32(_ptr(xg[g]), _ptr(outs[0]), _ptr(outs[1]), 1, _ptr(newx[g]), rows, mine, other, CHAIN_SKEW_US if g == 1 else 0,
-                                              c_void_p(side[g].cuda_stream)), 'pwv_iaf_affine_sync_f32')
-        keep.append((outs, xg, dil))
-        xg = newx
-    for g in range(2):
-        main.wait_stream(side[g])
-    global CHAIN_FORWARDS
-    CHAIN_FORWARDS += 1
-    return xg[0]
 
 
 def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,

@@ -23,7 +23,6 @@ import sys
 import numpy as np
 import torch
 
-from ._lib import PwvPersistError, PwvRangeError
 from .hparam import hparam as hp
 from .models import IAFVocoder
 from .variables import reset_default_store
@@ -82,13 +81,14 @@ def _load_mels(data_path, batch_size, length, device):
     return gt, torch.from_numpy(np.stack(mels)).to(device)
 
 
-def forward_over_ranks(mel, batch_size, length, device, make_model, noise_window, n_mels, hop, halo, group=None):
+def forward_over_ranks(mel, batch_size, length, device, make_model, noise_window, n_mels, hop, halo, group=None, allow_time_shards=True):
     """The forward of a job started with one process per GPU (WORLD_SIZE > 1; the reference is single-device,
     generate.py:47-49).  Rank 0 passes all mels [batch_size, t_mel, n_mels]; it gets all waveforms [batch_size, length, 1]
     back (other ranks: None).  Utterances shard across the ranks (distributed.generate_sharded); a batch smaller than the
     world shards in TIME instead, exactly (distributed.generate_time_sharded_ranks, halo = timeshard.chain_halo).  Every
     rank draws its share of ONE logistic-noise stream -- utterance i, sample t is counter i * length + t -- so the result
-    does not depend on how the job was cut.
+    does not depend on how the job was cut.  allow_time_shards=False (a model with a time-global normaliser, for which
+    overlap-and-discard is not exact) keeps a small batch on utterance shards: ranks beyond the batch idle.
       make_model(n, window) -> callable(mel [n, 1 + window/hop, n_mels], z [n, window, 1]) -> [n, window, 1]
       noise_window(n, first_sample, window, first_item) -> z [n, window, 1]"""
     import torch.distributed as dist
@@ -101,7 +101,7 @@ def forward_over_ranks(mel, batch_size, length, device, make_model, noise_window
             models[(n, window)] = make_model(n, window)
         return models[(n, window)]
 
-    if batch_size >= world:
+    if batch_size >= world or not allow_time_shards:
         lo, _ = shard_bounds(batch_size, world, rank)
         return generate_sharded(lambda m, zz: model_for(m.shape[0], length)(m, noise_window(m.shape[0], 0, length, lo)),
                                 mel, (1 + length // hop, n_mels), length, device, group=group)
@@ -145,21 +145,10 @@ def generate(case='default', ckpt=None, debug=False):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    pred = model(gt_wav, melspec, is_training=False)         # feed forward
-    try:
-        try:
-            model.verify()
-        except PwvPersistError as e:
-            # a persistent stack launch gave up (its workgroups were not all resident): the engine has switched to the
-            # per-layer launches; same arithmetic, rerun
-            print('%s\nre-running the forward with per-layer launches' % e)
-            pred = model(gt_wav, melspec, is_training=False)
-            model.verify()
-    except PwvRangeError as e:
-        # the reference computes in fp32 (models.py:81-82): outside the range of the split-fp16 arithmetic, rerun in it
-        print('%s\nre-running the forward with exact fp32 arithmetic' % e)
-        model = IAFVocoder(batch_size=batch_size, length=length, store=store, precision='f32')
-        pred = model(gt_wav, melspec, is_training=False)
+    # feed forward (generate.py:68).  The call returns a verified result: a persistent launch that gave up is rerun on per-layer
+    # launches, a forward that left the range of the split-fp16 arithmetic in exact fp32 -- on the same noise
+    # (engine.verified_call); what comes back is what the reference's fp32 sess.run would have produced, or an exception
+    pred = model(gt_wav, melspec, is_training=False)
     if ckpt:
         # tf.train.Saver.restore fails on a variable the checkpoint lacks (generate.py:59-63); here variables are
         # created lazily by the forward, so the coverage check comes after it
@@ -217,33 +206,36 @@ def _generate_over_ranks(store, batch_size, length, device, logdir, ckpt, debug)
     dist.broadcast(seed, src=0)                                         # one noise stream for the whole job
     seed = int(seed.item())
     halo = chain_halo(hp.model.dilations, hp.model.filter_width, hp.model.n_iaf, hop)
-    used = []
+
+    errors = []
 
     def make_model(n, window):
         m = IAFVocoder(batch_size=n, length=window, store=store)
-        used.append(m)
 
         def run(mel, z):
-            # checked before the result is gathered: a persistent launch that gave up (only with several processes on one GPU)
-            # has switched the engine to the per-layer launches; same arithmetic, rerun this rank's share
-            for attempt in (0, 1):
-                try:
-                    y = m(None, mel, is_training=False, z=z)
-                    torch.cuda.synchronize()
-                    engine.raise_if_persist_failed()
-                    return y
-                except PwvPersistError as e:
-                    if attempt:
-                        raise
-                    print('%s\nre-running the forward with per-layer launches' % e)
+            # a verified call: this rank's share is complete and checked (rerun on per-layer launches / in exact fp32 if need
+            # be) BEFORE it is gathered.  A failure must not leave the other ranks alone in the gather: hand back zeros, keep
+            # the collectives paired, and let the failure bit below stop every rank before anything is written
+            try:
+                return m(None, mel, is_training=False, z=z)
+            except Exception as e:
+                errors.append(e)
+                return torch.zeros((mel.shape[0], window, 1), dtype=torch.float32, device=device)
         return run
 
     def noise_window(n, first_sample, window, first_item):
         return engine.logistic_noise_window(n, length, first_sample, window, device, seed, first_item)
 
-    pred = forward_over_ranks(melspec, batch_size, length, device, make_model, noise_window, n_mels, hop, halo)
-    for m in used:
-        m.verify()
+    # a normaliser that reduces over time (modules.py:274-284) makes a time slice depend on the whole utterance: such a model
+    # shards by utterance only (ranks beyond the batch idle) -- timeshard.py is exact for causal FIR structure, nothing else
+    time_ok = 'in' not in (hp.model.normalize, hp.model.normalize_cond, hp.model.normalize_wavenet)
+    pred = forward_over_ranks(melspec, batch_size, length, device, make_model, noise_window, n_mels, hop, halo, allow_time_shards=time_ok)
+    flag = torch.tensor([1 if errors else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # rank 0 writes only what EVERY rank has verified
+    if int(flag.item()):
+        if errors:
+            raise errors[0]
+        raise RuntimeError('generate(): the forward failed on another rank; nothing was written')
     if ckpt and store.not_restored():
         missing = store.not_restored()
         raise KeyError('checkpoint %s does not hold %d of the model\'s %d variables: %s' % (ckpt, len(missing), len(store.vars), ', '.join(missing[:6])))

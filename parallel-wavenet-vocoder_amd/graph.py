@@ -1,10 +1,11 @@
 """The forward of an IAFVocoder captured once into a HIP graph and replayed.
 
-The path is ~130 dependent kernel launches per forward ("Launch structure"); eager, every one
-costs a host enqueue and leaves a gap in front of the next kernel.  Capturing the stream work (the launches of
-libpwv_hip.so on torch's current stream and on the two per-net side streams, including their fork / join events)
-into one graph removes the host from the loop: bit-identical results, 2 % faster at 160000 samples, 12 % at
-16000 samples, 37 % for the one-flow configuration (measured, tools/graph_bench.py).
+The path is 16 dependent kernel launches per forward with the persistent stack launch (~115 on the per-layer path;
+DESIGN.md section 4, "Launch structure"); eager, every one costs a host enqueue and leaves a gap in front of the next
+kernel.  Capturing the stream work (the launches of libpwv_hip.so on torch's current stream and, on the per-layer path,
+on the two per-net side streams with their fork / join events) into one graph removes the host from the loop:
+bit-identical results, 2 % faster at 160000 samples, 12 % at 16000 samples, 37 % for the one-flow configuration
+(measured, tools/graph_bench.py).
 
 No tracing and no compiler: the graph is exactly the launches `IAFVocoder.__call__` enqueues, with the buffers torch's
 graph-private pool handed out during capture.  Shapes are fixed at capture (batch, length); the mel and the noise
@@ -58,12 +59,29 @@ class GraphedVocoder(object):
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
             self.out = self.model(None, self.mel, is_training=False, z=self.z)
         self._version = self.store.version
+        self._mode = self._launch_mode()
+
+    @staticmethod
+    def _launch_mode():
+        """what decides WHICH launches a forward enqueues, besides the weights: a graph captured under another value is stale"""
+        return (engine.PERSIST, engine.TWO_STREAMS, engine.FOLD_FIRST, engine.FUSE_FIRST, engine.FUSE_HEAD, engine.HOIST_P,
+                engine.PERSIST_MAX_LAYERS, engine.PERSIST_MIN_UNITS, engine.DEFAULT_PRECISION)
+
+    def verify(self):
+        """Replays only enqueue: wait for them and raise like IAFVocoder.verify().  After a PwvPersistError the engine is on the
+        per-layer path; the graph is re-captured on it here, so the caller's rerun replays launches that can complete."""
+        try:
+            engine.verify_enqueued()
+        except engine._lib.PwvPersistError:
+            self._capture()
+            raise
 
     def __call__(self, melspec: torch.Tensor, z: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> torch.Tensor:
         """melspec [N, t_mel, n_mels]; z [N, length, 1] or None (sample Logistic(0,1), models.py:32-33).
-        Returns the graph's output buffer [N, length, 1]: valid until the next call (clone it to keep it)."""
-        if self.store.version != self._version:      # weights changed: the captured launches point at stale packs
-            self._capture()
+        Returns the graph's output buffer [N, length, 1]: valid until the next call (clone it to keep it).  Enqueue-only, like
+        IAFVocoder.__call__(verify=False): call verify() before reading the result."""
+        if self.store.version != self._version or self._mode != self._launch_mode():
+            self._capture()      # weights changed (the captured launches point at stale packs) or the engine switched launch paths
         if tuple(melspec.shape) != tuple(self.mel.shape):
             raise ValueError('melspec must be %s (fixed at capture), got %s' % (tuple(self.mel.shape), tuple(melspec.shape)))
         self.mel.copy_(melspec, non_blocking=True)

@@ -50,34 +50,41 @@ class IAFVocoder(object):
         return z
 
     # -- network (models.py:23-78) -------------------------------------------------------------------
-    def __call__(self, wav, melspec, is_training=False, name='iaf_vocoder', z=None):
+    def __call__(self, wav, melspec, is_training=False, name='iaf_vocoder', z=None, verify=None):
         """wav is unused by the forward (as in the reference); melspec [N, t_mel, n_mels] on the
         GPU.  ``z`` (optional, [N, length, 1]) replaces the logistic noise sampled at
-        models.py:32-33 so results are reproducible against the oracle."""
+        models.py:32-33 so results are reproducible against the oracle.
+
+        By default the call returns a VERIFIED result (engine.verified_call): it waits for its launches, and a forward whose
+        persistent launch gave up or whose operands left the range of the split-fp16 arithmetic is rerun (per-layer launches /
+        exact fp32) on the same noise before anything is handed back.  ``verify=False`` (or PWV_ASYNC=1) only enqueues, like
+        the C ABI; the caller then calls ``verify()`` before it reads the result."""
         store = self.store or get_default_store()
-        engine.raise_if_range_flag('an earlier call')       # sticky flags of forwards that have completed since
+        engine.raise_if_range_flag('an earlier call')       # sticky words of un-verified forwards that have completed since
         engine.raise_if_persist_failed()
-        engine.raise_if_sync_failed()
         melspec = engine._require_cuda_f32(melspec, 'melspec')
         if melspec.dim() != 3 or melspec.shape[1] != self.t_mel or melspec.shape[2] != hp.signal.n_mels:
             raise ValueError('melspec must be [N, %d, %d], got %s' % (self.t_mel, hp.signal.n_mels, tuple(melspec.shape)))
         n = melspec.shape[0]
+        if z is None:   # Logistic(0,1) noise, models.py:32-33 (drawn once: a rerun sees the same noise)
+            noise = self.sample_noise(n, melspec.device)
+        else:
+            noise = engine._require_cuda_f32(z, 'z')
+            if tuple(noise.shape) != (n, self.length, 1):
+                raise ValueError('z must be [%d, %d, 1], got %s' % (n, self.length, tuple(noise.shape)))
+        return engine.verified_call(lambda prec: self._forward(store, melspec, noise, is_training, name, prec or self.precision), verify)
+
+    def _forward(self, store, melspec, input, is_training, name, precision):
+        """models.py:23-78: condition, then the flows; only enqueues."""
         shared = bool(hp.model.get('shared_nets', False))
         with variable_scope(name):
             with variable_scope('cond'):
-                condition = self._condition(melspec, is_training, strides=[4, 4, 5], store=store)   # (n, t, h)
+                condition = self._condition(melspec, is_training, strides=[4, 4, 5], store=store, precision=precision)   # (n, t, h)
                 if hp.model.normalize_cond and condition is not None:
                     if isinstance(condition, RepeatedCondition):
                         condition = condition.materialize()
                     with variable_scope('normalize'):
                         condition = normalize(condition, is_training, hp.model.normalize_cond, store=store)
-
-            if z is None:   # Logistic(0,1) noise, models.py:32-33
-                input = self.sample_noise(n, melspec.device)
-            else:
-                input = engine._require_cuda_f32(z, 'z')
-                if tuple(input.shape) != (n, self.length, 1):
-                    raise ValueError('z must be [%d, %d, 1], got %s' % (n, self.length, tuple(input.shape)))
             flows = []
             for i in range(hp.model.n_iaf):
                 with variable_scope('iaf{}'.format(i)):
@@ -93,7 +100,7 @@ class IAFVocoder(object):
                         use_skip_connection=hp.model.use_skip_connection,
                         is_training=is_training,
                         normalize=hp.model.normalize_wavenet,
-                        store=store, precision=self.precision)
+                        store=store, precision=precision)
                     if shared:   # build extension: BASELINE.json configs[1]
                         net = WaveNet(quantization_channels=2, input_channels=1, name='shared', **kwargs)
                         iaf = SharedIAFLayer(batch_size=hp.train.batch_size, net=net)
@@ -104,14 +111,7 @@ class IAFVocoder(object):
                         iaf = LinearIAFLayer(batch_size=hp.train.batch_size, scaler=scaler, shifter=shifter)
                     flows.append(iaf)
             # the frame-rate projections of every net depend on the mel only: one GEMM for all flows, ahead of the first
-            engine.project_all([net for iaf in flows for net in iaf.nets()], condition, precision=self.precision)
-            # the common shape (two scalar nets per flow, no normaliser between the flows): the two nets' launch chains stay
-            # on their streams across the flows (engine.run_flow_chain); otherwise flow by flow
-            chained = None
-            if not shared and not hp.model.normalize:
-                chained = engine.run_flow_chain([iaf.nets() for iaf in flows], input, condition, precision=self.precision)
-            if chained is not None:
-                return chained
+            engine.project_all([net for iaf in flows for net in iaf.nets()], condition, precision=precision)
             for i, iaf in enumerate(flows):
                 input = iaf(input, condition)  # (n, t, h)
                 # normalization (identity at the default hparams), models.py:70
@@ -119,13 +119,11 @@ class IAFVocoder(object):
         return input
 
     def verify(self):
-        """Wait for the enqueued forwards and raise PwvRangeError if one of them left the range of the split-fp16
-        arithmetic (the reference computes in fp32, models.py:81-82; see include/pwv_hip.h "Range guard")."""
-        import torch
-        torch.cuda.synchronize()
-        engine.raise_if_persist_failed()
-        engine.raise_if_sync_failed()
-        engine.raise_if_range_flag()
+        """For callers of the enqueue-only form (verify=False / PWV_ASYNC=1): wait for the enqueued forwards and raise
+        PwvPersistError if a persistent launch gave up (the engine is on per-layer launches from then on: rerun) or
+        PwvRangeError if one left the range of the split-fp16 arithmetic (rerun with precision='f32'; the reference computes
+        in fp32, models.py:81-82; include/pwv_hip.h "Range guard")."""
+        engine.verify_enqueued()
 
     def _mel_limit(self, weights, store):
         """Largest |mel| for which every operand of the conditioning GEMMs stays inside fp16's range: each stage is
@@ -142,10 +140,11 @@ class IAFVocoder(object):
         return self._mel_limit_val
 
     # -- condition upsampling (models.py:105-136) ----------------------------------------------------
-    def _condition(self, melspec, is_training, strides, store):
+    def _condition(self, melspec, is_training, strides, store, precision=None):
         """The condition in the form the kernels want: a lazy RepeatedCondition for 'repeat'
         (projected at frame rate inside the nets), a materialised [N, T, C] tensor for
         'transposed_conv', None otherwise."""
+        precision = precision or self.precision
         hop = hp.signal.hop_length
         assert (np.prod(np.array(strides)) == hop)                              # models.py:106
         if self.length % hop != 0:
@@ -167,11 +166,11 @@ class IAFVocoder(object):
                 self._tconv_key = key
                 self._tconv_mats = [w[0].permute(2, 0, 1).reshape(w.shape[3], stride * C).contiguous() for w, stride in zip(ws, strides)]
             wmats = self._tconv_mats
-            if (self.precision or engine.DEFAULT_PRECISION) == 'f16x3':
+            if (precision or engine.DEFAULT_PRECISION) == 'f16x3':
                 engine.range_check_op(melspec, self._mel_limit(wmats, store))
             for i, stride in enumerate(strides):
                 wmat = wmats[i]
-                cond = engine.linear_op(cond, wmat, None, relu=True, precision=self.precision)   # models.py:118-120
+                cond = engine.linear_op(cond, wmat, None, relu=True, precision=precision)   # models.py:118-120
                 input_channels = C
                 length *= stride
                 cond = cond.reshape(n * length, C)
@@ -182,10 +181,10 @@ class IAFVocoder(object):
             return engine.crop_time_op(cond, length - hop, hop // 2)            # models.py:124
         elif method == 'repeat':
             w = get_variable('dense', [1, n_mels, C], store=store)
-            if (self.precision or engine.DEFAULT_PRECISION) == 'f16x3':
+            if (precision or engine.DEFAULT_PRECISION) == 'f16x3':
                 engine.range_check_op(melspec, self._mel_limit([w[0]], store))
             frames = engine.linear_op(melspec.reshape(n * t_mel, n_mels), w[0], None, relu=True,
-                                      precision=self.precision)                              # models.py:128-130
+                                      precision=precision)                              # models.py:128-130
             return RepeatedCondition(frames.reshape(n, t_mel, C), hop, hop // 2, self.length)      # models.py:131-133
         return None
 

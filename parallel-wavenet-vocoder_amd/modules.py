@@ -227,15 +227,19 @@ class WaveNet(object):
         return ok and self.condition_channels == 80
 
     # -- network ---------------------------------------------------------------------------------------
-    def __call__(self, input_batch, condition_batch=None):
+    def __call__(self, input_batch, condition_batch=None, verify=None):
+        """modules.py:129-166.  Called on its own it returns a verified result like IAFVocoder.__call__ (engine.verified_call:
+        rerun on per-layer launches / in exact fp32 if a sticky word is raised); nested in an IAF layer / the vocoder it only
+        enqueues and the outermost call verifies."""
         if self.fused_supported(condition_batch):
-            return engine.run_nets([self], input_batch, condition_batch, precision=self.precision)[0]
+            return engine.verified_call(lambda prec: engine.run_nets([self], input_batch, condition_batch, precision=prec or self.precision)[0], verify)
         return self._call_unfused(input_batch, condition_batch)
 
     def _call_unfused(self, input_batch, condition_batch):
         """Architectures outside the fused kernels' shape (other widths / channel counts /
-        normalisers): composed on the GPU from pwv_causal_conv_f32 (every convolution, 1x1
-        included) and torch device elementwise ops.  Slow path, same math (modules.py:129-259)."""
+        normalisers): composed on the GPU from pwv_causal_conv_f32 (every convolution, 1x1 included) and the
+        library's elementwise kernels (pwv_gate_f32, pwv_add_f32, pwv_channel_affine_f32, pwv_instance_norm_f32).
+        Exact fp32, no range guard needed.  Slow path, same math (modules.py:129-259)."""
         if isinstance(condition_batch, RepeatedCondition):
             condition_batch = condition_batch.materialize()
         x = engine._require_cuda_f32(input_batch, 'input_batch')
@@ -312,16 +316,22 @@ class LinearIAFLayer(object):
     def nets(self):
         return [self.scaler, self.shifter]
 
-    def __call__(self, input, condition=None):
+    def __call__(self, input, condition=None, verify=None):
         '''
         input = (n, t, h), condition = (n, t, h)
         '''
+        return engine.verified_call(lambda prec: self._enqueue(input, condition, prec), verify)
+
+    def _enqueue(self, input, condition, prec=None):
         sc, sh = self.scaler, self.shifter
         both_fused = (isinstance(sc, WaveNet) and isinstance(sh, WaveNet) and sc.fused_supported(condition)
                       and sh.fused_supported(condition) and engine._same_structure(sc, sh)
                       and sc.precision == sh.precision)
         if both_fused:
-            scale, shift = engine.run_nets([sc, sh], input, condition, precision=sc.precision)
+            scale, shift = engine.run_nets([sc, sh], input, condition, precision=prec or sc.precision)
+        elif prec is not None and isinstance(sc, WaveNet) and isinstance(sh, WaveNet):
+            scale = engine.run_nets([sc], input, condition, precision=prec)[0] if sc.fused_supported(condition) else sc(input, condition)
+            shift = engine.run_nets([sh], input, condition, precision=prec)[0] if sh.fused_supported(condition) else sh(input, condition)
         else:
             scale = sc(input, condition)
             shift = sh(input, condition)
@@ -345,8 +355,15 @@ class SharedIAFLayer(object):
     def nets(self):
         return [self.net]
 
-    def __call__(self, input, condition=None):
-        y = self.net(input, condition)                      # [N, T, 2]
+    def __call__(self, input, condition=None, verify=None):
+        return engine.verified_call(lambda prec: self._enqueue(input, condition, prec), verify)
+
+    def _enqueue(self, input, condition, prec=None):
+        net = self.net
+        if prec is not None and net.fused_supported(condition):
+            y = engine.run_nets([net], input, condition, precision=prec)[0]
+        else:
+            y = net(input, condition)                       # [N, T, 2]
         x = engine._require_cuda_f32(input, 'input')
         flat = y.reshape(-1)
         return engine.iaf_affine_op(x, flat, flat[1:], 2)

@@ -20,6 +20,13 @@ import torch
 EMA_SUFFIX = '/ExponentialMovingAverage'
 
 
+def is_trainable(name: str) -> bool:
+    """tf.trainable_variables(): every variable the path creates is trainable except the moving statistics of
+    tf.layers.batch_normalization (modules.py:266).  The reference keeps EMA shadows of the trainable ones only
+    (models.py:72-75) and, with hp.train.use_ema, restores ONLY those (generate.py:57-63)."""
+    return not (name.endswith('/moving_mean') or name.endswith('/moving_variance'))
+
+
 class VariableStore:
     _uid_counter = 0
 
@@ -32,6 +39,8 @@ class VariableStore:
         self.version = 0            # bumped on every change; packed-weight caches key on it
         self.restored = set()                       # names set from a checkpoint / dict (what tf.train.Saver.restore covered)
         self.restored_without_shadow = set()        # ... of those, under use_ema, the ones whose shadow the checkpoint lacks
+        self.left_at_init = set()                   # non-trainable variables a use_ema restore deliberately did not touch
+        self._ema_restores = 0                      # load_dict(use_ema=True) calls so far
 
     # -- tf.get_variable -------------------------------------------------------------------
     def get_variable(self, name: str, shape: Sequence[int], initializer: Optional[str] = None) -> torch.Tensor:
@@ -69,10 +78,16 @@ class VariableStore:
 
     def load_dict(self, weights: Dict[str, np.ndarray], use_ema: bool = False, strict: bool = False) -> int:
         """Restore by TF variable name.  With ``use_ema`` a shadow ``<name>/ExponentialMovingAverage``
-        wins over the raw variable (generate.py:59-63).  Returns the number of variables set."""
+        wins over the raw variable (generate.py:59-63) -- and, as there, ONLY trainable variables are restored: the Saver's
+        var_list holds tf.trainable_variables('iaf_vocoder') and nothing else, so the moving statistics of a batch norm keep
+        what global_variables_initializer gave them (zeros / ones, generate.py:56).  Returns the number of variables set."""
         loaded = 0
+        self._ema_restores += 1 if use_ema else 0
         names = set(k[:-len(EMA_SUFFIX)] if k.endswith(EMA_SUFFIX) else k for k in weights)
         for name in sorted(names):
+            if use_ema and not is_trainable(name.split(':')[0]):
+                self.left_at_init.add(name.split(':')[0])
+                continue
             key = name + EMA_SUFFIX if (use_ema and name + EMA_SUFFIX in weights) else name
             if key not in weights:
                 if strict:
@@ -91,7 +106,7 @@ class VariableStore:
         """Model variables under `scope` that a use_ema restore took from the RAW variable because the checkpoint has no
         ``<name>/ExponentialMovingAverage`` for them.  The reference's Saver maps every trainable variable of 'iaf_vocoder'
         to its shadow name (generate.py:59-63) and fails on a missing key; callers that mirror it treat this list as an error."""
-        return sorted(k for k in self.vars if k in self.restored_without_shadow and k.startswith(scope))
+        return sorted(k for k in self.vars if k in self.restored_without_shadow and k.startswith(scope) and is_trainable(k))
 
     def load_npz(self, path: str, use_ema: bool = False) -> int:
         with np.load(path) as z:
@@ -112,8 +127,12 @@ class VariableStore:
         raise FileNotFoundError('no checkpoint at %s (.npz or TF V2 .index/.data)' % path)
 
     def not_restored(self):
-        """Model variables that exist but were never set from a checkpoint (i.e. carry their random initialisation)."""
-        return sorted(k for k in self.vars if k not in self.restored)
+        """Model variables that exist but were never set from a checkpoint (i.e. carry their random initialisation) although
+        the restore should have covered them.  The non-trainable ones a use_ema restore leaves alone like the reference
+        (load_dict) are not listed -- nor are non-trainable variables at all once such a restore has happened (the reference's
+        Saver does not look for them, generate.py:57-63)."""
+        ema_restore = bool(self.left_at_init) or bool(self._ema_restores)
+        return sorted(k for k in self.vars if k not in self.restored and not (ema_restore and not is_trainable(k)))
 
     def save_npz(self, path: str) -> None:
         np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.vars.items()})
@@ -122,7 +141,7 @@ class VariableStore:
         return {k: v.detach().cpu().numpy() for k, v in self.vars.items()}
 
     def trainable_variables(self, scope: str = '') -> Iterable[str]:
-        return [k for k in self.vars if k.startswith(scope)]
+        return [k for k in self.vars if k.startswith(scope) and is_trainable(k)]
 
 
 _default_store: Optional[VariableStore] = None

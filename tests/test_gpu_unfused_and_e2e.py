@@ -336,6 +336,30 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
         assert 'scattered over 2 ranks' in j['sharded_generate'] and j['f32_exact']['value'] > 0
 
 
+@pytest.mark.parametrize('extra,want', [(['--case', 'bench/c1'], 'scattered over 1 ranks'),
+                                        (['--case', 'bench/c1', '--length', '32000', '--shard', 'time'], 'cut into 1 time shards')])
+def test_bench_takes_every_rccl_branch_at_world_size_one(extra, want):
+    """PWV_BENCH_FORCE_DIST=1: `python bench.py --gpus 1` initialises the `nccl` backend (RCCL) at world size 1 and takes every
+    distributed branch the driver's 8-GPU run takes -- init_process_group('nccl', device_id=...), barriers, the MAX all-reduce
+    of the elapsed time and the give-up vote on DEVICE tensors, generate_sharded / generate_time_sharded_ranks over nccl
+    broadcast / scatter / gather with device chunks.  What is left for N > 1 is the fabric, not the code path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PWV_BENCH_FORCE_DIST='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'PWV_BENCH_DRYRUN', 'PWV_BENCH_DRYRUN_ONE_GPU'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-f32-exact'] + extra
+    res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 1 and j['rccl_ranks'] == 1 and j['backend'] == 'nccl' and j['value'] > 0
+    assert want in j['sharded_generate'] and j['sharded_generate'].endswith('ok')
+
+
 def test_device_mel_frontend_matches_numpy_restatement(gpu):
     """pwv_wav_to_mel_db_f32 (STFT -> Slaney mel -> dB -> [-1, 1]) against the numpy restatement of
     data_load.py:51-54 / audio.py:102-141,232-243,254-286,341-356 on speech-like and edge-case signals; <= 1e-5."""

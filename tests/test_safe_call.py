@@ -1,0 +1,204 @@
+"""The contract of the reference-shaped calls (engine.verified_call): a call returns a VERIFIED result by default.
+
+CPU part: the control flow with the device taken out (stubs for the stream / the sticky words).
+-m gpu part: `pred = model(None, mel, is_training=False); pred.cpu()` -- generate.py:38,68 -- with a mel far outside the
+range of the split-fp16 arithmetic gives the exact-fp32 result, never inf; a persistent give-up inside the call is repaired
+inside the call; verify=False hands the duty to verify()."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iaf_oracle as O
+from tests.util import TOL_F32, set_hparams, small_cfg
+
+
+class _Stream:
+    def __init__(self, log):
+        self.log = log
+
+    def synchronize(self):
+        self.log.append('sync')
+
+
+@pytest.fixture()
+def stub_engine(monkeypatch):
+    from pwv_amd import engine
+    log = []
+    state = {'persist': 0, 'range': False}
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: _Stream(log))
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(engine, 'persist_status', lambda: state['persist'])
+    monkeypatch.setattr(engine, 'clear_persist_status', lambda: state.__setitem__('persist', 0))
+    monkeypatch.setattr(engine, 'range_flag_raised', lambda: state['range'])
+    monkeypatch.setattr(engine, 'clear_range_flag', lambda: state.__setitem__('range', False))
+    monkeypatch.setattr(engine, 'ASYNC', False)
+    saved = engine.PERSIST
+    yield engine, log, state
+    engine.PERSIST = saved
+
+
+def test_clean_call_synchronises_once_and_returns(stub_engine):
+    engine, log, state = stub_engine
+    runs = []
+    out = engine.verified_call(lambda prec: (runs.append(prec), 'y')[1])
+    assert out == 'y' and runs == [None] and log == ['sync']
+
+
+def test_give_up_inside_the_call_is_rerun_on_per_layer_launches(stub_engine):
+    engine, log, state = stub_engine
+    engine.PERSIST = 'auto'
+    runs = []
+
+    def run(prec):
+        runs.append((prec, engine.PERSIST))
+        if len(runs) == 1:
+            state['persist'], state['range'] = 4, True      # the give-up, and garbage downstream tripping the range guard
+        return 'y%d' % len(runs)
+    assert engine.verified_call(run) == 'y2'
+    assert runs == [(None, 'auto'), (None, False)] and engine.PERSIST is False and not state['range']
+
+
+def test_range_flag_inside_the_call_is_rerun_in_f32(stub_engine):
+    engine, log, state = stub_engine
+    runs = []
+
+    def run(prec):
+        runs.append(prec)
+        if prec is None:
+            state['range'] = True
+        return prec
+    assert engine.verified_call(run) == 'f32' and runs == [None, 'f32'] and log == ['sync', 'sync']
+
+
+def test_a_rerun_that_still_fails_raises(stub_engine):
+    from pwv_amd._lib import PwvRangeError
+    engine, log, state = stub_engine
+
+    def run(prec):
+        state['range'] = True          # e.g. a NaN in the input: no arithmetic repairs that
+        return prec
+    with pytest.raises(PwvRangeError):
+        engine.verified_call(run)
+
+
+def test_nested_async_and_opted_out_calls_only_enqueue(stub_engine):
+    engine, log, state = stub_engine
+    inner = []
+
+    def outer(prec):
+        inner.append(engine.verified_call(lambda p: 'inner'))      # e.g. the IAF layers inside IAFVocoder.__call__
+        assert log == []                                           # ... no synchronisation per flow
+        return 'outer'
+    assert engine.verified_call(outer) == 'outer' and inner == ['inner'] and log == ['sync']
+    del log[:]
+    state['range'] = True
+    assert engine.verified_call(lambda p: 'raw', verify=False) == 'raw' and log == [] and state['range']
+    engine.ASYNC = True
+    assert engine.verified_call(lambda p: 'raw') == 'raw' and log == []
+    assert engine.verified_call(lambda p: p, verify=True) == 'f32'      # an explicit verify=True wins over PWV_ASYNC
+
+
+# ---- on the device ----------------------------------------------------------------------------------------------------
+def _model(gpu, cfg, length, n, precision=None, seed=6):
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=seed))
+    return IAFVocoder(batch_size=n, length=length, store=store, precision=precision), store
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
+def test_reference_shaped_call_never_returns_inf(gpu, method):
+    """generate.py:38,68 as written -- no z, no verify() -- with |mel| ~ 1e5: the split-fp16 forward trips the range guard,
+    the call reruns itself in exact fp32 on the same noise and returns what a precision='f32' model returns, bit for bit."""
+    from pwv_amd import engine
+    from pwv_amd.models import IAFVocoder
+    cfg = small_cfg(cond_upsample_method=method)
+    n, length = 2, 480
+    mel, _ = O.synthetic_inputs(n, length, cfg)
+    mel_t = torch.from_numpy((mel * 1e5).astype(np.float32)).to(gpu)
+    model, store = _model(gpu, cfg, length, n)
+    model.noise_seed = 77
+    pred = model(None, mel_t, is_training=False)
+    got = pred.cpu()
+    assert bool(torch.isfinite(got).all())
+    assert not engine.range_flag_raised() and engine.persist_status() == 0      # nothing left behind for the next caller
+    z = engine.logistic_noise_op((n, length, 1), gpu, seed=77, offset=0)         # the noise that call drew
+    m32 = IAFVocoder(batch_size=n, length=length, store=store, precision='f32')
+    want = m32(None, mel_t, is_training=False, z=z)
+    assert torch.equal(got, want.cpu())
+    with np.errstate(all='ignore'):
+        ref = O.iaf_vocoder_forward(O.init_weights(cfg, seed=6), (mel * 1e5).astype(np.float32), z.cpu().numpy(), cfg)
+    assert np.abs(got.numpy() - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())      # (fp32 itself, on saturated gates)
+    # in range the same model object answers in its own arithmetic again
+    mel1 = torch.from_numpy(mel).to(gpu)
+    y = model(None, mel1, is_training=False, z=z).cpu().numpy()
+    assert np.abs(y - O.iaf_vocoder_forward(O.init_weights(cfg, seed=6), mel, z.cpu().numpy(), cfg)).max() <= TOL_F32
+
+
+@pytest.mark.gpu
+def test_opting_out_hands_the_duty_to_verify(gpu):
+    from pwv_amd._lib import PwvRangeError
+    cfg = small_cfg()
+    mel, z = O.synthetic_inputs(1, 480, cfg)
+    model, _ = _model(gpu, cfg, 480, 1)
+    bad = torch.from_numpy((mel * 1e5).astype(np.float32)).to(gpu)
+    model(None, bad, is_training=False, z=torch.from_numpy(z).to(gpu), verify=False)      # returns at once, unverified
+    with pytest.raises(PwvRangeError):
+        model.verify()
+    model.verify()                                                                         # reported once, then clean
+
+
+@pytest.mark.gpu
+def test_give_up_inside_a_call_is_repaired_inside_the_call(gpu, monkeypatch):
+    """A persistent launch that gives up during THIS call (the word is poked from the host while the call is enqueuing: a real
+    give-up needs a second process on the GPU, tools/co_tenant_check.sh) -> the call reruns on per-layer launches and hands
+    back exactly what the per-layer path computes."""
+    from pwv_amd import engine
+    cfg = O.ModelConfig(dilations=[[1, 2, 4, 8, 16, 32], [1, 2, 4, 8, 16, 32]], n_iaf=2)
+    n, length = 1, 16000
+    mel, z = O.synthetic_inputs(n, length, cfg)
+    mel_t, z_t = torch.from_numpy(mel).to(gpu), torch.from_numpy(z).to(gpu)
+    model, _ = _model(gpu, cfg, length, n, seed=2)
+    saved = engine.PERSIST
+    try:
+        engine.PERSIST = False
+        want = model(None, mel_t, is_training=False, z=z_t).clone()
+        engine.PERSIST = True
+        engine.persist_status()                 # (materialises the word's address)
+        real, poked = engine._run_stack_persist, []
+
+        def spy(*a, **k):
+            real(*a, **k)
+            if not poked:
+                poked.append(1)
+                ctypes.c_int.from_address(engine._persist_status_addr).value = 4
+        monkeypatch.setattr(engine, '_run_stack_persist', spy)
+        got = model(None, mel_t, is_training=False, z=z_t)
+        assert poked and engine.PERSIST is False and engine.persist_status() == 0
+        assert torch.equal(got, want)
+    finally:
+        engine.PERSIST = saved
+
+
+@pytest.mark.gpu
+def test_wavenet_and_iaf_layer_called_directly_are_safe_too(gpu):
+    """modules.WaveNet / LinearIAFLayer used on their own (generate.py:11-13 imports them): a flow input beyond the range of
+    the split-fp16 arithmetic comes back as the exact-fp32 result, not inf."""
+    from pwv_amd.modules import LinearIAFLayer, WaveNet
+    from pwv_amd.variables import VariableStore, variable_scope
+    store = VariableStore(device=gpu)
+    kw = dict(batch_size=1, dilations=[1, 2, 4, 8], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
+              quantization_channels=1, use_biases=True, condition_channels=None, use_skip_connection=False, store=store)
+    with variable_scope('t'):
+        sc, sh = WaveNet(name='scalar', **kw), WaveNet(name='shifter', **kw)
+        sc32, sh32 = WaveNet(name='scalar', precision='f32', **kw), WaveNet(name='shifter', precision='f32', **kw)
+    x = (torch.randn((1, 640, 1), generator=torch.Generator().manual_seed(3)) * 3e5).to(gpu)
+    y = sc(x)
+    assert bool(torch.isfinite(y).all()) and torch.equal(y, sc32(x))
+    out = LinearIAFLayer(1, sc, sh)(x)
+    assert bool(torch.isfinite(out).all()) and torch.equal(out, LinearIAFLayer(1, sc32, sh32)(x))

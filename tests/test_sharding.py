@@ -118,7 +118,7 @@ def test_time_sharded_ranks_gloo_world2(n_utts, length, tiles, with_z):
     assert ret['err'] <= 1e-6
 
 
-def _job_worker(rank, world, port, batch, length, ret):
+def _job_worker(rank, world, port, batch, length, ret, allow_time=True):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -140,7 +140,8 @@ def _job_worker(rank, world, port, batch, length, ret):
                 return z + 0.5 * zp[:, :window] + c
             return model
 
-        out = forward_over_ranks(mel if rank == 0 else None, batch, length, torch.device('cpu'), make_model, noise_window, n_mels, hop, halo)
+        out = forward_over_ranks(mel if rank == 0 else None, batch, length, torch.device('cpu'), make_model, noise_window, n_mels, hop, halo,
+                                 allow_time_shards=allow_time)
         ret['calls%d' % rank] = list(calls)
         if rank == 0:
             want = make_model(batch, length)(mel, noise_window(batch, 0, length, 0))
@@ -163,3 +164,13 @@ def test_generate_under_a_launcher_shards_utterances_or_time(batch, length):
         assert ret['calls0'] == [(2, length)] and ret['calls1'] == [(1, length)]
     else:
         assert ret['calls0'] == [(1, 2000)] and ret['calls1'] == [(1, 2000 + 160)]
+
+
+def test_a_time_global_normaliser_keeps_a_small_batch_on_utterance_shards():
+    """normalize* = 'in' reduces over the whole time axis (modules.py:274-284): overlap-and-discard is not exact for it, so
+    generate() passes allow_time_shards=False and ONE utterance on two ranks runs whole on rank 0 while rank 1 idles."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_job_worker, args=(2, _free_port(), 1, 4000, ret, False), nprocs=2, join=True)
+    assert ret['shape'] == (1, 4000, 1) and ret['equal']
+    assert ret['calls0'] == [(1, 4000)] and ret['calls1'] == []

@@ -224,3 +224,30 @@ def test_use_ema_restore_reports_variables_without_a_shadow():
     assert store.ema_missing() == ['iaf_vocoder/b'] and float(store.vars['iaf_vocoder/a'][0]) == 0.0
     store.load_dict({'iaf_vocoder/b/ExponentialMovingAverage': np.full((3,), 2, np.float32)}, use_ema=True)
     assert store.ema_missing() == []
+
+
+def test_use_ema_restore_covers_trainable_variables_only():
+    """generate.py:57-63: with hp.train.use_ema the Saver's var_list is {ema.average_name(v): v for v in
+    tf.trainable_variables('iaf_vocoder')} -- the moving statistics of a batch norm (modules.py:266) are not trainable, have no
+    shadow (models.py:72-75) and are not restored at all: they keep global_variables_initializer's zeros / ones.  A valid
+    reference checkpoint of a normalize='bn' model must therefore load without a "no shadow" error, and leave them alone."""
+    from pwv_amd.variables import VariableStore
+    bn = 'iaf_vocoder/iaf0/scalar/causal_layer/normalize/batch_normalization/'
+    w = {bn + 'gamma': np.full((4,), 2, np.float32), bn + 'gamma/ExponentialMovingAverage': np.full((4,), 3, np.float32),
+         bn + 'beta': np.zeros((4,), np.float32), bn + 'beta/ExponentialMovingAverage': np.ones((4,), np.float32),
+         bn + 'moving_mean': np.full((4,), 5, np.float32), bn + 'moving_variance': np.full((4,), 7, np.float32)}
+    store = VariableStore(device='cpu')
+    for leaf, init in (('gamma', 'ones'), ('beta', 'zeros'), ('moving_mean', 'zeros'), ('moving_variance', 'ones')):
+        store.get_variable(bn + leaf, [4], init)
+    store.load_dict(w, use_ema=True)
+    assert store.ema_missing() == [] and store.not_restored() == []
+    assert float(store.vars[bn + 'gamma'][0]) == 3.0 and float(store.vars[bn + 'beta'][0]) == 1.0
+    assert float(store.vars[bn + 'moving_mean'][0]) == 0.0 and float(store.vars[bn + 'moving_variance'][0]) == 1.0
+    assert sorted(store.left_at_init) == [bn + 'moving_mean', bn + 'moving_variance']
+    assert bn + 'moving_mean' not in store.trainable_variables('iaf_vocoder') and bn + 'gamma' in store.trainable_variables('iaf_vocoder')
+    # without use_ema the Saver restores every variable of the graph, the statistics included (generate.py:56: var_list = None)
+    store2 = VariableStore(device='cpu')
+    store2.load_dict(w, use_ema=False)
+    assert float(store2.vars[bn + 'moving_mean'][0]) == 5.0 and float(store2.vars[bn + 'gamma'][0]) == 2.0
+    store2.get_variable(bn.replace('iaf0', 'iaf1') + 'moving_mean', [4], 'zeros')
+    assert store2.not_restored() == [bn.replace('iaf0', 'iaf1') + 'moving_mean']      # ... and misses one it lacks
