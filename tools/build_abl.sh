@@ -1,14 +1,15 @@
 #!/bin/bash
-# Builds timing-only variants of the library for the additive-perturbation A/B runs of tools/ab.sh:
-#   tools/build_abl.sh ADD_LDS ADD_MFMA ADD_VALU ADD_P2 ADD_X2 ABL_NOP ABL_PMFMA
+# Builds timing-only variants of the library for the A/B runs of tools/ab.sh:
+#   tools/build_abl.sh ABL_NOXB16
 # Each NAME becomes tools/abl_so/libpwv_NAME.so, compiled with -DPWV_NAME from a scratch copy of csrc/ with
-# tools/probes/perturb.patch applied (the probes are kept out of the product sources).  Results are WRONG by design for
-# the ABL_* variants and unchanged for the ADD_* ones; only the step time is of interest.
+# tools/probes/persist_probes.patch applied (the probes are kept out of the product sources).  Results are WRONG by design
+# for the ABL_* variants; only the step time is of interest.  (Rounds 1-2 used perturb.patch against the per-layer kernel
+# of that time -- ADD_LDS / ADD_MFMA / ADD_VALU / ADD_P2 / ADD_X2 / ABL_NOP / ABL_PMFMA; git history has it.)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
 cp -r "$root/parallel-wavenet-vocoder_amd/csrc" "$tmp/csrc"
-(cd "$tmp" && patch -s -p2 -d . < "$root/tools/probes/perturb.patch")
+(cd "$tmp/csrc" && patch -s -p1 < "$root/tools/probes/persist_probes.patch")
 mkdir -p "$root/tools/abl_so"
 for v in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950:xnack- --offload-arch=gfx950:xnack+ -O3 -std=c++17 -shared -fPIC -DPWV_$v -I"$root/include" -I"$tmp/csrc" \
