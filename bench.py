@@ -214,9 +214,11 @@ def main():
             sk.close()
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
-        # keep stdout to the one JSON line: RCCL's version banner (NCCL_DEBUG=VERSION/INFO) would land there
-        if os.environ.get('NCCL_DEBUG', '').upper() in ('VERSION', 'INFO', ''):
-            os.environ['NCCL_DEBUG'] = 'WARN'
+        # keep stdout to the one JSON line.  RCCL writes its debug stream to STDOUT by default: the version banner
+        # ("RCCL version : ..." at NCCL_DEBUG >= VERSION) and NCCL WARN lines (seen on the GPU box: "alt_rsmi.cc NCCL WARN Could
+        # not read node # 9" at init AND at teardown, glued to whatever was printed last).  Leave NCCL_DEBUG as the caller set it
+        # (unset = silent) and send the stream to stderr; the JSON line is printed after the process group is gone (below).
+        os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = 'gloo' if dryrun else 'nccl'                              # 'nccl' IS RCCL on ROCm (xGMI)
@@ -615,11 +617,14 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline and not control:
             from oracle.iaf_oracle import ModelConfig          # the oracle is only ever the CPU leg, never the timed path
             result['cpu_baseline'] = cpu_baseline(ModelConfig.from_hparam(hp), args.cpu_seconds)
-        sys.stdout.flush()
-        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the LAST thing on stdout, on a line of its own whatever a library printed before it without a newline
+        sys.stdout.flush()
+        sys.stdout.write(('\n' if dist is not None else '') + json.dumps(result) + '\n')
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':
