@@ -49,6 +49,16 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LAYER_FLOP_PER_SAMPLE = 2 * (2 * 64 * 128 + 64 * 64)      # 40960
 LAYER_BYTES_PER_SAMPLE = 2 * 64 * 4                       # 512
 
+# what holds the split-fp16 unit body below both nominal roofs (the files are in profiles/ and tools/probes/)
+LIMITER_K1P = ('neither nominal roof binds: by arithmetic intensity (3 x 80 = 240 fp16-FLOP/B < 312) the HBM roof is the nominal one, but the unit body is '
+               'bound by ISSUE and CLOCK.  (1) issue: MFMA and VALU instructions of the two waves of a SIMD issue serially (tools/probes/coissue.hip: '
+               '32 cycles per MFMA + 2-2.7 per VALU instruction, same counts on 8 workgroups at 2.4 GHz), so 120 MFMA + ~790 VALU + 96 transcendentals per '
+               '32-row unit put the matrix pipe at 49-52 % busy inside the persistent launch (SQ_VALU_MFMA_BUSY_CYCLES, per-configuration table of the '
+               'newest profiles/rNN_*_configs.md); (2) clock: rocm-smi reads the 1400 W package cap with sclk at 1.7-1.9 of 2.4 GHz under this bench '
+               '(profiles/rNN_*_power_clock.txt), so added work costs time in proportion and idle time comes back as clock (tools/idle_probe.py).  '
+               'The 3-term split cannot shed MFMAs at fp32 accuracy; HBM traffic is 1.04-1.10 x algorithmic; configurations whose working set leaves the '
+               '256 MB Infinity Cache (C4, C5) run the unit at the same rate as C3, so HBM residency is not the limit either')
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -173,6 +183,27 @@ def latest_profile_json(suffix):
     import glob
     c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*' + suffix)))
     return c[-1] if c else None
+
+
+def attach_profile(roof, args, rows):
+    """`traffic` (HBM bytes per launch from the PMC passes) and the rocprofv3-timed launch duration of the dominant kernel, from
+    the committed profile set of THIS configuration (profiles/rNN_x_<case>[_<precision>]_hbm_traffic.json, written by
+    tools/profile_round4_summarize.py from the same command under rocprofv3) -- with the roofline fraction recomputed from
+    that duration next to the live, event-timed one."""
+    name = args.case.replace('bench/', '') + ('' if args.precision == 'f16x3' else '_' + args.precision)
+    tpath = latest_profile_json('_%s_hbm_traffic.json' % name)
+    if not tpath:
+        return
+    with open(tpath) as f:
+        tj = json.load(f)
+    if tj.get('rows') != rows or tj.get('kernel_pattern', '').split('<')[0] not in roof['kernel']:
+        return
+    roof['traffic'] = tj['traffic_bytes_per_launch']
+    roof['traffic_over_algorithmic'] = tj['ratio']
+    roof['traffic_source'] = os.path.relpath(tpath, ROOT)
+    if 'rocprof_kernel_us' in tj:
+        roof['rocprof_kernel_us'] = tj['rocprof_kernel_us']
+        roof['frac_rocprof'] = tj['algorithmic_bytes_per_launch'] / (tj['rocprof_kernel_us'] * 1e-6) / 1e9 / PEAK_HBM_GBS
 
 
 def main():
@@ -423,7 +454,8 @@ def main():
             ref = torch.cuda.Event(enable_timing=True)
             ref.record()
             try:
-                for _ in range(max(1, min(args.steps, 5))):
+                n_event_fwd = max(1, min(args.steps, 5))
+                for _ in range(n_event_fwd):
                     eager_step()
                 torch.cuda.synchronize()
                 engine.raise_if_persist_failed()
@@ -446,14 +478,14 @@ def main():
                 kinds.setdefault((cnt, gnets), []).append(e - b)
             med = {k: sorted(v)[len(v) // 2] for k, v in kinds.items()}
             total_ms = sum(med[(cnt, gnets)] for _, _, cnt, gnets in pers)
-            timing = {'kind': 'persist', 'launches': len(pers), 'total_ms': total_ms, 'net_layers': sum(cnt * g for _, _, cnt, g in pers),
+            timing = {'kind': 'persist', 'forwards': n_event_fwd, 'launches': len(pers), 'total_ms': total_ms, 'net_layers': sum(cnt * g for _, _, cnt, g in pers),
                       'launch_ms': [min(med.values()), max(med.values())],
                       'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3], 'first_net_layers': first_runs}
         elif chains:
             busy = merged_length([(b, e) for b, e, _, _ in chains])
             total_ms = sum(e - b for b, e, _, _ in chains)
             launches = sum(cnt for _, _, cnt, _ in chains)
-            timing = {'kind': 'per-layer', 'layer_ms': total_ms / launches, 'launches': launches, 'nets_per_launch': chains[0][3],
+            timing = {'kind': 'per-layer', 'forwards': n_event_fwd, 'layer_ms': total_ms / launches, 'launches': launches, 'nets_per_launch': chains[0][3],
                       'overlap': total_ms / busy if busy > 0 else 1.0}
 
     if rank == 0:
@@ -514,35 +546,43 @@ def main():
             alg_flop = rows * timing['net_layers'] * LAYER_FLOP_PER_SAMPLE
             ach_gbs = alg_bytes / (timing['total_ms'] * 1e-3) / 1e9
             ach_tf = alg_flop / (timing['total_ms'] * 1e-3) / 1e12
-            roof = {'kernel': 'stack_persist_kernel (persistent dataflow launch: %s residual layers x %d nets per launch, split-fp16 MFMA)'
-                              % ('/'.join(str(c) for c in timing['layers_per_launch']), timing['nets_per_launch']),
+            arith = {'f16x3': 'split-fp16 MFMA', 'f32': 'exact fp32 MFMA', 'f16': 'fp16 rows + fp16 MFMA'}[args.precision]
+            roof = {'kernel': 'stack_persist_kernel (persistent dataflow launch: %s residual layers x %d nets per launch, %s)'
+                              % ('/'.join(str(c) for c in timing['layers_per_launch']), timing['nets_per_launch'], arith),
                     'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS,
                     'launches_timed': timing['launches'], 'launch_ms_median_by_kind': timing['launch_ms'],
                     'us_per_layer_pair': timing['total_ms'] * 1e3 / (timing['net_layers'] / timing['nets_per_launch']),
                     'alg_bytes_per_net_layer': rows * layer_bytes, 'alg_flop_per_net_layer': rows * LAYER_FLOP_PER_SAMPLE,
+                    # what ONE forward launches of this kernel (tools/profile_round4_summarize.py prices the PMC / rocprof passes with it)
+                    'launches_per_forward': timing['launches'] // timing['forwards'], 'net_layers_per_forward': timing['net_layers'] // timing['forwards'],
+                    'first_net_layers_per_forward': timing['first_net_layers'] // timing['forwards'],
+                    'alg_bytes_per_forward': alg_bytes // timing['forwards'],
                     'traffic': None,
                     'note': 'achieved = algorithmic bytes (512 B per sample, net and layer) of the layers a launch runs / its duration, '
                             'HIP events around each persistent launch on its stream (median per kind of launch over the timed forwards)'}
-            tpath = latest_profile_json('_hbm_traffic.json')
-            if args.case == 'bench/c3' and rows == 160000 and tpath:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get('kernel', '').startswith('stack_persist') or 'stack_persist' in tj.get('kernel', ''):
-                    roof['traffic'] = tj['traffic_bytes_per_net_layer']
-                    roof['traffic_source'] = os.path.relpath(tpath, ROOT)
-                    for k in ('rocprof_kernel_us', 'rocprof_us_per_layer_pair'):
-                        if k in tj:
-                            roof[k] = tj[k]
-            result['roofline'] = roof
-            # issued: three fp16 MFMAs per algorithmic one -- except in a net's layer 0 when it runs folded onto its four input
-            # scalars (engine.FOLD_FIRST): ONE k-step of 16 for the filter|gate convolution instead of eight
-            folded = args.precision == 'f16x3' and engine.FOLD_FIRST and timing['first_net_layers'] > 0
-            first_issued = 3 * 2 * (16 * 128 + 64 * 64) if folded else 3 * LAYER_FLOP_PER_SAMPLE
-            issued_tf = rows * ((timing['net_layers'] - timing['first_net_layers']) * 3 * LAYER_FLOP_PER_SAMPLE
-                                + timing['first_net_layers'] * first_issued) / (timing['total_ms'] * 1e-3) / 1e12
-            roof['first_layer'] = 'folded onto its four input scalars (one MFMA k-step for filter|gate)' if folded else 'as every other layer'
-            result['roofline_mfma'] = {'bound': 'mfma', 'achieved': issued_tf, 'peak': PEAK_F16_MFMA_TFLOPS,
-                                       'unit': 'TFLOP/s (fp16 MFMA FLOPs issued: 3x algorithmic, a folded layer 0 less)', 'frac': issued_tf / PEAK_F16_MFMA_TFLOPS}
+            attach_profile(roof, args, rows)
+            cond_flop = 2 * int(hp.model.condition_channels) * 128 if hp.model.cond_upsample_method == 'transposed_conv' else 0
+            if args.precision == 'f32':
+                # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => the matrix pipe is the roof, the HBM view sits beside it
+                result['roofline'] = dict(roof, bound='mfma', achieved=ach_tf, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach_tf / PEAK_F32_MFMA_TFLOPS)
+                result['roofline_hbm'] = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS}
+            elif args.precision == 'f16':
+                result['roofline'] = roof
+                tf16 = rows * timing['net_layers'] * (LAYER_FLOP_PER_SAMPLE + cond_flop) / (timing['total_ms'] * 1e-3) / 1e12
+                result['roofline_mfma'] = {'bound': 'mfma', 'achieved': tf16, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (one fp16 product per term)',
+                                           'frac': tf16 / PEAK_F16_MFMA_TFLOPS}
+            else:
+                result['roofline'] = roof
+                # issued: three fp16 MFMAs per algorithmic one -- except in a net's layer 0 when it runs folded onto its four input
+                # scalars (engine.FOLD_FIRST): ONE k-step of 16 for the filter|gate convolution instead of eight
+                folded = engine.FOLD_FIRST and timing['first_net_layers'] > 0
+                first_issued = 3 * 2 * (16 * 128 + 64 * 64) if folded else 3 * LAYER_FLOP_PER_SAMPLE
+                issued_tf = rows * ((timing['net_layers'] - timing['first_net_layers']) * 3 * LAYER_FLOP_PER_SAMPLE
+                                    + timing['first_net_layers'] * first_issued) / (timing['total_ms'] * 1e-3) / 1e12
+                roof['first_layer'] = 'folded onto its four input scalars (one MFMA k-step for filter|gate)' if folded else 'as every other layer'
+                roof['limiter'] = LIMITER_K1P
+                result['roofline_mfma'] = {'bound': 'mfma', 'achieved': issued_tf, 'peak': PEAK_F16_MFMA_TFLOPS,
+                                           'unit': 'TFLOP/s (fp16 MFMA FLOPs issued: 3x algorithmic, a folded layer 0 less)', 'frac': issued_tf / PEAK_F16_MFMA_TFLOPS}
         elif timing is not None:
             layer_ms, nets_per_launch = timing['layer_ms'], timing['nets_per_launch']
             per_sample = 1 if hp.model.cond_upsample_method == 'transposed_conv' else 0
@@ -560,16 +600,6 @@ def main():
                               'MEASURED: sum of the chains\' event intervals / length of their union (the scalar and shifter chains of a '
                               'flow run side by side on two HIP streams)' if nets_per_flow // nets_per_launch > 1
                               else 'one launch covers all nets of the flow'}
-            tpath = latest_profile_json('_hbm_traffic.json')
-            if args.precision == 'f16x3' and args.case == 'bench/c3' and rows == 160000 and tpath:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if 'traffic_bytes_per_launch' in tj:
-                    # the PMC passes count bytes per launch of one net; a G = 2 launch moves twice that
-                    common['traffic'] = tj['traffic_bytes_per_launch'] * bytes_per_launch / tj['algorithmic_bytes_per_launch']
-                    common['traffic_source'] = os.path.relpath(tpath, ROOT)
-                    if 'rocprof_kernel_us' in tj:
-                        common['rocprof_kernel_us'] = tj['rocprof_kernel_us']
             if args.precision == 'f32':
                 # exact-fp32 MFMA: 80 FLOP/B >> fp32 machine balance (19.7) => matrix-pipe bound
                 result['roofline'] = dict(kernel='layer_f32_kernel (fused gated-residual layer, %d nets/launch)' % nets_per_launch,
@@ -589,12 +619,8 @@ def main():
                 result['roofline'] = dict(kernel='layer_f16x3_kernel<0,%d,0> (fused gated-residual layer%s, %d nets/launch)' % (per_sample, ', per-sample condition' if per_sample else '', nets_per_launch),
                                           bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
                                           frac=ach_gbs / PEAK_HBM_GBS, **common)
-                result['roofline']['limiter'] = ('two stacked limits, neither of them HBM: (1) issue -- every VALU instruction takes 2-2.7 cycles of matrix-pipe '
-                                                 'time on a SIMD (tools/probes/coissue.hip, same cycle counts on 8 workgroups at 2.4 GHz), so 120 MFMA + ~700 VALU '
-                                                 'per 32-row unit give 44-46 % matrix-pipe busy (profiles/r02_g_sq_counters.md); (2) clock -- rocm-smi reads '
-                                                 '1380-1400 W of the 1400 W package cap with sclk held at 1.82-1.92 of 2.4 GHz during this bench '
-                                                 '(profiles/r02_power_clock.md, r02_i_power_clock.md).  By arithmetic intensity (240 fp16-FLOP/B < 312) the HBM roof is the nominal one '
-                                                 '-- DESIGN.md section 4, K1 item 6 and K1p')
+                attach_profile(result['roofline'], args, rows)
+                result['roofline']['limiter'] = LIMITER_K1P
                 result['roofline_mfma'] = {'bound': 'mfma', 'achieved': 3 * ach_tf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp16 MFMA FLOPs issued = 3x algorithmic)',
                                            'frac': 3 * ach_tf / PEAK_F16_MFMA_TFLOPS}
         per_gpu = rows * args.steps / elapsed if time_shard else value / n_gpus      # (time shards: the samples a GPU actually computes, look-back included)

@@ -368,8 +368,8 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
                           pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation; PWV_PREC_F16X3 / PWV_PREC_F32 without a
- * per-sample condition, PWV_PREC_F16 with or without one) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
+ * A run of consecutive RESIDUAL layers (out_mode PWV_OUT_RESIDUAL, no skip accumulation, no per-sample condition,
+ * PWV_PREC_F16X3 or PWV_PREC_F32) of G nets as ONE persistent launch: the inner iterations of the loop in WaveNet.__call__
  * (modules.py:138-143) without a kernel boundary, a weight-staging phase and a ramp-up / ramp-down per layer.
  *   x_ring[g]  three full-size tile32 buffers (N*T rows x 64) per net, `ring_stride` floats apart (>= pwv_tile32_floats(N*T, 64)).
  *   Layer j of the run reads buffer (j + 2 + r) % 3 and writes buffer (j + r) % 3, r = ring_rotation: the input of the run is
@@ -382,7 +382,7 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
  * csrc/pwv_stack_persist.hip has the protocol.  The call enqueues (unless `workspace_clean`) a kernel that zeroes the control words and one kernel
  * (grid <= one workgroup per CU; max_workgroups > 0 limits it further, e.g. to share the chip with another stream).
  *   pwv_persist_workspace_bytes   size of `workspace` (device memory, 256-byte aligned, contents don't care) for the shape in
- *                                 `args` (G, N, T, n_layers, dilations, precision, max_workgroups, min_units_per_workgroup are read);
+ *                                 `args` (G, N, T, n_layers, dilations, max_workgroups, min_units_per_workgroup are read);
  *                                 0 = this shape cannot run as a persistent launch (pwv_last_error says why): use the
  *                                 per-layer launches
  *   pwv_persist_status(&p)        process-wide sticky int32 in pinned host memory: 0, or != 0 once a launch gave up
@@ -394,8 +394,8 @@ typedef struct pwv_persist_args {
     int G;
     int n_layers;                                 /* 2..32 layers in this launch */
     const int* dilations;                         /* HOST array [n_layers] */
-    float* x_ring[PWV_MAX_NETS];                  /* (PWV_PREC_F16: fp16 tile32 blocks, as everywhere in that mode) */
-    size_t ring_stride;                           /* ELEMENTS (floats; halfs in PWV_PREC_F16) between two of a net's three buffers, a multiple of 8 */
+    float* x_ring[PWV_MAX_NETS];
+    size_t ring_stride;                           /* floats between two of a net's three buffers */
     int ring_rotation;                            /* 0, 1 or 2 */
     const float* packed_layers[PWV_MAX_NETS];     /* the run's first layer */
     size_t packed_layer_stride;
@@ -407,11 +407,11 @@ typedef struct pwv_persist_args {
     size_t workspace_bytes;
     int workspace_clean;                          /* != 0: `workspace` is all zero on entry (fresh, or last used by this entry point, which
                                                    * zeroes it again before it returns the chip): no zeroing kernel is enqueued */
-    int precision;                                /* PWV_PREC_* (packed_layers packed accordingly) */
+    int precision;                                /* PWV_PREC_F16X3 or PWV_PREC_F32 (packed_layers packed accordingly) */
     int max_workgroups;                           /* 0 = one per CU */
     int min_units_per_workgroup;                  /* short inputs: use fewer workgroups rather than ranges below this (0 = 4) */
-    /* optional (not PWV_PREC_F16): the run starts with the net's layer 0, which evaluates the causal layer itself from the scalar
-     * input [N*T] (pwv_layer_args.x_first: same operations, same bits); buffer (2 + r) % 3 is then not read */
+    /* optional: the run starts with the net's layer 0, which evaluates the causal layer itself from the scalar input [N*T]
+     * (pwv_layer_args.x_first: same operations, same bits); buffer (2 + r) % 3 is then not read */
     const float* x_first;
     const float* causal_filter[PWV_MAX_NETS];
     float x_limit;                                /* range guard on x_first (pwv_layer_args.x_limit / range_flag) */
@@ -421,11 +421,6 @@ typedef struct pwv_persist_args {
      * eight): the same function (h[t] is linear in x[t-1], x[t]), rounded differently -- within the path's tolerance of the
      * unfolded form, not bit-identical to it */
     const float* first_fold[PWV_MAX_NETS];
-    /* PWV_PREC_F16 only: the per-sample condition (pwv_cond_to_f16 blocks; cond_channels = 80) or NULL / 0.  Two layers' `hi`
-     * weights WITH their condition weights fit the LDS in this mode (122 KB), so BASELINE config 5 runs persistently; the
-     * other arithmetics refuse a per-sample condition here (80 + 40 KB per layer: one layer's worth of LDS) -- per-layer launches. */
-    const void* cond;
-    int cond_channels;
 } pwv_persist_args;
 
 size_t pwv_persist_workspace_bytes(const pwv_persist_args* args);

@@ -150,14 +150,12 @@ class PersistArgs(Structure):
         ('x_limit', ctypes.c_float),
         ('range_flag', c_void_p),
         ('first_fold', c_void_p * PWV_MAX_NETS),
-        ('cond', c_void_p),
-        ('cond_channels', c_int),
     ]
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into the in-tree shared library."""
-    srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', h) for h in ('pwv_common.h', 'pwv_layer_common.h', 'pwv_f16x3.h', 'pwv_h16.h')] + [os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
+    srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', h) for h in ('pwv_common.h', 'pwv_layer_common.h', 'pwv_f16x3.h')] + [os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
     if os.environ.get('PWV_LIB'):
         return LIB_PATH            # an explicitly chosen library is never rebuilt
     if not force and os.path.exists(LIB_PATH):

@@ -33,7 +33,6 @@
 //    per-layer path.  All workgroups must be resident (grid <= CUs, one workgroup per CU by its LDS size).
 // Results are bit-identical to the per-layer launches (same per-unit arithmetic): tests/test_gpu_persist.py.
 #include "pwv_f16x3.h"
-#include "pwv_h16.h"
 
 #include <cstdlib>
 
@@ -44,32 +43,17 @@
 
 namespace pwv {
 
-// arithmetic of the unit body
-constexpr int kArF16x3 = 0, kArF32 = 1, kArH16 = 2;
-
 constexpr int kSlotFull = kA1Size + kA2Size;   // floats of a layer's matrices: filter|gate (hi+lo) + dense (hi+lo) = 81,920 B
+constexpr int kSlot = kSlotFull - 256;         // held in LDS: everything but the last 1 KB fragment of the dense matrix
+constexpr int kBiasF = 2 * kSlot;              // [2 slots][64] dense bias
+constexpr int kCtlF = kBiasF + 128;            // control ints: [0] task counter, [1] abort, [2..3] flag bytes, [8 + j] waves that left layer j
 constexpr int kCtlInts = 40;
-constexpr int kMaxUnitsWg = 864;               // units per workgroup (one "layers completed" byte each)
-
-// LDS map of one workgroup, in floats: [slot 0][slot 1][2 x 64 dense bias][control ints][causal filter 2 x 64][done bytes]
-//   split-fp16 / fp32: a slot holds everything of a layer's matrices but the LAST 1 KB fragment of the dense matrix (a unit
-//   reads that one from global memory): 2 x 80,896 B + 2 KB of small state = all 160 KB of the CU;
-//   fp16 mode: a slot holds the `hi` halves only -- filter|gate 32 KB + dense 8 KB (+ per-sample condition weights 20 KB):
-//   two layers WITH their condition weights fit (122 KB), which is what lets BASELINE config 5 run persistently.
-template <int AR, bool COND>
-struct PersistLds {
-    static constexpr bool kHalf = AR == kArH16;
-    static constexpr int kSlot = kHalf ? (kH_END - (COND ? 0 : kH_END - kH_AC)) * 4 : kSlotFull - 256;
-    static constexpr int kBiasF = 2 * kSlot;              // [2 slots][64] dense bias
-    static constexpr int kCtlF = kBiasF + 128;            // control ints: [0] task counter, [1] abort, [2..3] flag bytes, [4] waves that have exited, [8 + j] waves that left layer j
-    static constexpr int kCfF = kCtlF + kCtlInts;         // causal filter [2][64] (a run that starts with the net's layer 0, see x_first)
-    static constexpr int kDoneB = (kCfF + 128) * 4;       // byte offset of the per-unit "layers completed" bytes
-    static constexpr int kFloats = (kDoneB + kMaxUnitsWg) / 4;
-    static constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
-    static constexpr int kUnitBytes = kHalf ? 4096 : 8192;      // one 32-row unit of the residual ring (64 channels)
-    static constexpr int kRowF = kHalf ? 16 : 32;               // 4-byte registers one row takes per lane
-};
-static_assert(PersistLds<kArF16x3, false>::kFloats == 40960, "the split-fp16 / fp32 map fills the CU's LDS exactly");
+constexpr int kLdsFloats = 40960;              // all 160 KB of the CU
+constexpr int kCfF = kCtlF + kCtlInts;       // causal filter [2][64] (a run that starts with the net's layer 0, see x_first)
+constexpr int kDoneB = (kCfF + 128) * 4;                   // byte offset of the per-unit "layers completed" bytes
+constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 864 units per workgroup
+constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
+constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
 constexpr int kMaxPLayers = 32;
 constexpr long long kWaitTicks = 2000000;      // a wave gives up after 20 ms of the chip-wide 100 MHz clock (normal waits: microseconds)
 constexpr int kProgStride = 32;                // ints between two workgroups' progress words (own 128-byte lines)
@@ -96,7 +80,6 @@ struct PersistParams {
     const float* fold0[PWV_MAX_NETS];      // optional: layer 0's filter|gate GEMM folded onto the four scalars (pwv_pack_first_fold_f16x3 / _f32)
     float x_limit;                         // range guard of the split-fp16 arithmetic on x_first (include/pwv_hip.h)
     int* range_flag;
-    const void* cond;                      // fp16 mode: per-sample condition (pwv_cond_to_f16 blocks, 80 channels) or NULL
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
 };
 
@@ -175,14 +158,8 @@ __device__ __forceinline__ void gemm_groups_dense(FR&& fr, f32x16 (&acc)[2], f32
     }
 }
 
-template <int AR, bool COND>
+template <bool F32>
 __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams p) {
-    static_assert(!COND || AR == kArH16, "a per-sample condition inside the persistent launch: fp16 mode only (two layers WITH their condition weights must fit the LDS)");
-    typedef PersistLds<AR, COND> M;
-    constexpr bool F32 = AR == kArF32, H16 = AR == kArH16;
-    constexpr int kSlot = M::kSlot, kBiasF = M::kBiasF, kCtlF = M::kCtlF, kCfF = M::kCfF, kDoneB = M::kDoneB, kLdsFloats = M::kFloats;
-    constexpr int kSeenLB = M::kFlagB, kSeenRB = M::kFlagB + 1, kWreadyB = M::kFlagB + 2, kTrueB = M::kFlagB + 4;
-    constexpr int kUnitBytes = M::kUnitBytes, kRowF = M::kRowF, kRowLoads = kRowF / 4;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,14 +211,8 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const float* src = packed_n + (size_t)layer * p.packed_stride + lane * 4;
         float* dst = lds + slot * kSlot;
 #pragma clang loop unroll(disable)
-        for (int c = first; c < kSlot / 256; c += step) {
-            int so = c * 256;      // float offset in the packed layer of the 1 KB chunk that lands in chunk c of the slot
-            if constexpr (H16) {
-                // the `hi` halves of the split-fp16 sections: filter|gate (32 chunks at kA1), dense (8 at kA2), condition (20 at kLayerBase)
-                so = c < 32 ? c * 256 : (c < 40 ? kA2 + (c - 32) * 256 : kLayerBase + (c - 40) * 256);
-            }
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + c * 256), 16, 0, 0);
-        }
+        for (int c = first; c < kSlot / 256; c += step)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 256), (lptr_t)(dst + c * 256), 16, 0, 0);
         if (first == 0 && lane < 16)      // dense bias [2 h][32]
             __builtin_amdgcn_global_load_lds((gptr_t)(src + kSlotFull), (lptr_t)(lds + kBiasF + slot * 64), 16, 0, 0);
     };
@@ -257,34 +228,22 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     // scalar offset operand of the load / store.  sc1 loads: L2-served, never the CU's L1.
     const __amdgpu_buffer_rsrc_t ring_rs = [&]() {
         const unsigned long long a = (unsigned long long)p.ring[net];
-        const unsigned long long span = (unsigned long long)p.ring_stride * (H16 ? 4ull : 8ull) + (unsigned long long)p.units * kUnitBytes;
+        const unsigned long long span = (unsigned long long)p.ring_stride * 8ull + (unsigned long long)p.units * 8192ull;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
         return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, __builtin_amdgcn_readfirstlane((unsigned)span), 0x00020000);
     }();
-    const int slot_bytes = (int)(p.ring_stride * (H16 ? 2 : 4));      // (ring_stride counts elements: floats, or halfs in the fp16 mode)
+    const int slot_bytes = (int)(p.ring_stride * 4);
     auto in_soff = [&](int j) -> int { return ((j + 2 + p.rot) % 3) * slot_bytes; };
     auto out_soff = [&](int j) -> int { return ((j + p.rot) % 3) * slot_bytes; };
-    // byte offset of lane (t, h)'s first 16-byte chunk of `row`; its further chunks follow at 1 KB steps (8 per fp32 row, 4 per fp16 row)
-    auto toff = [&](int row) -> int { return (row >> 5) * kUnitBytes + h * 512 + (row & 31) * 16; };
+    auto toff = [&](int row) -> int { return ((row >> 5) * 2048 + h * 128 + (row & 31) * 4) * 4; };
 
     // x[t-d] / x[t] rows of one unit -> registers
-    // (fp16 mode: a row is 4 chunks of 8 halfs, carried bit for bit in 16 "float" registers; cd = the per-sample condition's 5 chunks)
-    auto load_x = [&](int j, int unit, float (&xb)[kRowF], float (&xc)[kRowF], float (&cd)[20]) {
+    auto load_x = [&](int j, int unit, float (&xb)[32], float (&xc)[32]) {
         int row, rc, nn, t;
         bool valid;
         unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
         const int d = dil_of(j);
         const bool has_prev = t >= d;
-        if constexpr (COND) {
-            const char* c0 = reinterpret_cast<const char*>(p.cond) + (size_t)(rc >> 5) * (32 * kCondC * 2) + h * 512 + (rc & 31) * 16;
-#pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(c0 + s5 * 1024);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cd[4 * s5 + e] = v[e];
-            }
-        }
-        if constexpr (!H16) {
         if (p.x_first && j == 0) {
             // layer 0 of the net: the four scalars its two rows are functions of (x[t], x[t-1], x[t-d], x[t-d-1]; zero left of
             // the utterance start); rebuilt into rows at the top of the unit (layer_f16x3_kernel's FIRST variant)
@@ -294,21 +253,20 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             xb[0] = has_prev ? x1[rc - (has_prev ? d : 0)] : 0.f;
             xb[1] = t >= d + 1 ? x1[rc - (t >= d + 1 ? d + 1 : 0)] : 0.f;
 #pragma unroll
-            for (int k = 2; k < kRowF; ++k) xb[k] = xc[k] = 0.f;      // (every element written on every path: the arrays stay in registers)
+            for (int k = 2; k < 32; ++k) xb[k] = xc[k] = 0.f;      // (every element written on every path: the arrays stay in registers)
             return;
-        }
         }
         const int so = in_soff(j);
         const int oc = toff(rc), ob = toff(has_prev ? rc - d : rc);
 #pragma unroll
-        for (int g = 0; g < kRowLoads; ++g) {
+        for (int g = 0; g < 8; ++g) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, oc + g * 1024, so, 16));
 #pragma unroll
             for (int e = 0; e < 4; ++e) xc[4 * g + e] = v[e];
         }
         auto load_b = [&](bool keep) {
 #pragma unroll
-            for (int g = 0; g < kRowLoads; ++g) {
+            for (int g = 0; g < 8; ++g) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, ob + g * 1024, so, 16));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xb[4 * g + e] = keep ? v[e] : 0.f;
@@ -430,7 +388,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     int j = 0;
     int u = locate(__builtin_amdgcn_readfirstlane(claim()), j);
     int claim_v = claim();                 // the task after that
-    float rxb[kRowF], rxc[kRowF], rcd[20];      // the rows (and the condition chunks) of the task in hand, requested a unit ahead
+    float rxb[32], rxc[32];
     bool war_ok = true;                    // (of the task in hand; its RAW side is satisfied when it starts)
     PT_DECL
 #ifdef PWV_PTRACE
@@ -445,7 +403,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     // (its input was complete before it started and the ring slot it writes has no earlier reader), so this loop never waits;
     // tasks are layer-major, so it ends when the wave's next task is a layer-1 one, and the general loop's first-task code
     // takes over.  (As a branch INSIDE the general loop the two accumulator sets cost it 60-80 spilled registers.)
-    if constexpr (!H16) {
     if (p.x_first && p.fold0[net]) {
         const float* Af = lds;                                                    // layer 0's weights: slot 0
         const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + kA1Size);
@@ -591,7 +548,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             u = u2;
         }
     }
-    }
     if (u >= 0) {
         // the first task of the general loop: nothing was prefetched (after the folded loop: drain and publish its last unit first)
         flush_owed();
@@ -600,7 +556,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const unsigned bad = eval(dep_addr(j, u));
         if (bad & kRawMask) wait_deps(j, u, kRawMask, j, 4);
         war_ok = (bad & kWarMask) == 0;
-        if (!dead) load_x(j, u, rxb, rxc, rcd);
+        if (!dead) load_x(j, u, rxb, rxc);
     }
     int lv_j = j;                          // layer voff / vneed currently describe
 
@@ -632,7 +588,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             bad2 = eval(dep_addr(j2, u2));
         }
 
-        if constexpr (!H16) {
         if (p.x_first && j == 0) {
             // rebuild this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; the operation order of
             // iaf_front_kernel / the FIRST variant of the per-layer kernel: round(x[t-1] w0), then fma(x[t], w1, .)
@@ -650,7 +605,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     rxb[4 * g + e] = has_prev ? vb : 0.f;
                 }
             }
-        }
         }
         const float* bias = lds + kBiasF + (j & 1) * 64 + h * 32;
         float o[32];
@@ -670,12 +624,10 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         // producers are done (normally they are a layer-sweep old); otherwise behind this unit's stores, after a wait
         auto prefetch_next = [&]() {
             if (u2 >= 0 && !(bad2 & kRawMask)) {
-                load_x(j2, u2, rxb, rxc, rcd);
+                load_x(j2, u2, rxb, rxc);
             } else {      // (ends the old rows' live ranges: without it they would occupy 64 registers through both GEMMs)
 #pragma unroll
-                for (int k = 0; k < kRowF; ++k) rxb[k] = rxc[k] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 20; ++k) rcd[k] = 0.f;
+                for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -731,41 +683,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         }
                     }
                 });
-        } else if constexpr (H16) {
-            // ---- fp16 mode (pwv_layer_h16.hip's unit): the rows as loaded ARE the B operands, one fp16 product per term ----
-            const f16x8* W = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);      // [filter|gate hi][dense hi][condition hi]
-            f16x8 b[8];      // k-steps 0..3 = x[t-d], 4..7 = x[t]
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                b[s4] = __builtin_bit_cast(f16x8, f32x4{rxb[4 * s4], rxb[4 * s4 + 1], rxb[4 * s4 + 2], rxb[4 * s4 + 3]});
-                b[4 + s4] = __builtin_bit_cast(f16x8, f32x4{rxc[4 * s4], rxc[4 * s4 + 1], rxc[4 * s4 + 2], rxc[4 * s4 + 3]});
-            }
-            f16x8 cb[5];
-            if constexpr (COND) {
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5)
-                    cb[s5] = __builtin_bit_cast(f16x8, f32x4{rcd[4 * s5], rcd[4 * s5 + 1], rcd[4 * s5 + 2], rcd[4 * s5 + 3]});
-            }
-            settle_top();
-            if constexpr (COND) gemm_h<5, 4>(W + kH_AC, lane, acc, [&](int s5) -> f16x8 { return cb[s5]; });
-            gemm_h<8, 4>(W + kH_A1, lane, acc, [&](int s8) -> f16x8 { return b[s8]; });
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[tl * 16 + r] = gate_act(acc[tl][r], acc[tl + 2][r]);
-            f16x8 oh[4];
-            oh[0] = to_h8<0>(o);
-            oh[1] = to_h8<8>(o);
-            oh[2] = to_h8<16>(o);
-            oh[3] = to_h8<24>(o);
-            // dense 64 -> 64; accumulator starts at x[t] + dense_bias (register r of tile it <-> half r & 7 of chunk 2 it + (r >> 3))
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[it][r] = (float)b[4 + 2 * it + (r >> 3)][r & 7] + bias[it * 16 + r];
-            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
-            prefetch_next();
-            gemm_h<4, 2>(W + kH_A2, lane, acc2, [&](int s4) -> f16x8 { return oh[s4]; });
         } else {
             const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
             const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
@@ -847,23 +764,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             // units the right neighbour reads as x[t-d] in the next layer are stored write-through
             const int dn = dil_of(j + 1 < L ? j + 1 : j);
             const bool shared = u + ((dn + 31) >> 5) >= u_end;
-            if constexpr (H16) {
-                if (valid) {
-                    float y[32];
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) y[i] = acc2[i >> 4][i & 15];
-                    const f16x8 yh[4] = {to_h8<0>(y), to_h8<8>(y), to_h8<16>(y), to_h8<24>(y)};
-                    if (shared) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yh[s4]), ring_rs, oo + s4 * 1024, so, kAuxWriteThrough);
-                    } else {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yh[s4]), ring_rs, oo + s4 * 1024, so, PWV_PERSIST_STORE_AUX);
-                    }
-                }
-            } else {
             if (valid) {
                 if (shared) {
 #pragma unroll
@@ -882,7 +782,6 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 }
             }
         }
-        }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- move on ------------------------------------------------------------------------------------------------------
@@ -896,7 +795,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             wait_deps(j2, u2, kRawMask, lv_j, 4);
             PT_END(2);
             if (dead) break;
-            load_x(j2, u2, rxb, rxc, rcd);
+            load_x(j2, u2, rxb, rxc);
         }
         j = j2;
         u = u2;
@@ -966,7 +865,7 @@ int pwv_persist_status(int** status) {
 
 struct PersistPlan { int units, nwg, per_wg, last_wg, reach_wgs, xcd_map; };
 
-static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int max_wgs, int min_units, int unit_bytes, PersistPlan& pl) {
+static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int max_wgs, int min_units, PersistPlan& pl) {
     PWV_CHECK_ARG(G >= 1 && G <= PWV_MAX_NETS, "persistent stack: G=%d out of range", G);
     PWV_CHECK_ARG(n_layers >= 2 && n_layers <= kMaxPLayers && dil, "persistent stack: 2..%d layers per launch, got %d", kMaxPLayers, n_layers);
     PWV_CHECK_ARG(rows >= 1 && rows < (1ll << 31) - 256, "persistent stack: bad N*T");
@@ -977,7 +876,7 @@ static int persist_plan(int G, long long rows, int n_layers, const int* dil, int
         dmax = dil[j] > dmax ? dil[j] : dmax;
     }
     pl.units = (int)((rows + 31) / 32);
-    PWV_CHECK_ARG((long long)pl.units * unit_bytes * 3 < (1ll << 32), "persistent stack: the ring of three buffers exceeds the 4 GB reach of a buffer descriptor");
+    PWV_CHECK_ARG((long long)pl.units * 8192 < (1ll << 32), "persistent stack: buffers beyond the 4 GB reach of a buffer descriptor");
     int wgs = cus / G;                                  // every workgroup must be resident: one per CU (its LDS is the whole CU's)
     if (max_wgs > 0 && max_wgs / G < wgs) wgs = max_wgs / G;
     PWV_CHECK_ARG(wgs >= 1, "persistent stack: no workgroups");
@@ -1004,8 +903,7 @@ size_t pwv_persist_workspace_bytes(const pwv_persist_args* a) {
     PersistPlan pl;
     const int cus = device_cus();
     if (!a) { set_error(PWV_EINVAL, "pwv_persist_workspace_bytes: NULL argument"); return 0; }
-    if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup,
-                     a->precision == PWV_PREC_F16 ? 4096 : 8192, pl) != PWV_OK) return 0;
+    if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl) != PWV_OK) return 0;
     return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);      // progress words + the abort word + the exit counter
 }
 
@@ -1015,16 +913,10 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
     PersistParams p{};
     PersistPlan pl;
-    const bool half16 = a->precision == PWV_PREC_F16;
-    int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, half16 ? 4096 : 8192, pl);
+    int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl);
     if (rc != PWV_OK) return rc;
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_stack_persist_f32: bad N/T");
-    PWV_CHECK_ARG(a->precision >= PWV_PREC_F32 && a->precision <= PWV_PREC_F16, "pwv_wavenet_stack_persist_f32: unsupported precision %d", a->precision);
-    PWV_CHECK_ARG(!a->cond || (half16 && a->cond_channels == kCondC),
-                  "pwv_wavenet_stack_persist_f32: a per-sample condition runs persistently in PWV_PREC_F16 only (%d channels; the other arithmetics "
-                  "cannot hold two layers with their condition weights in LDS: use the per-layer launches)", kCondC);
-    PWV_CHECK_ARG((a->cond_channels > 0) == (a->cond != nullptr), "pwv_wavenet_stack_persist_f32: cond / cond_channels mismatch");
-    PWV_CHECK_ARG(!half16 || !a->x_first, "pwv_wavenet_stack_persist_f32: PWV_PREC_F16 runs start behind layer 0 (x_first is not supported)");
+    PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32, "pwv_wavenet_stack_persist_f32: precision must be PWV_PREC_F16X3 or PWV_PREC_F32");
     PWV_CHECK_ARG(a->proj_row_stride % 4 == 0 && a->cond_hop >= 0, "pwv_wavenet_stack_persist_f32: bad projection arguments");
     PWV_CHECK_ARG(a->workspace_bytes >= pwv_persist_workspace_bytes(a), "pwv_wavenet_stack_persist_f32: workspace too small");
     PWV_CHECK_ARG(((uintptr_t)a->workspace & 255) == 0, "pwv_wavenet_stack_persist_f32: workspace must be 256-byte aligned");
@@ -1039,8 +931,8 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
         p.proj[g] = a->proj[g];
     }
     PWV_CHECK_HIP(pwv_persist_status(&p.status) == PWV_OK ? hipSuccess : hipErrorUnknown);
-    PWV_CHECK_ARG(a->ring_stride >= (size_t)pl.units * 2048 && a->ring_stride % 8 == 0,
-                  "pwv_wavenet_stack_persist_f32: ring_stride smaller than one tile32 buffer (%lld elements) or not a multiple of 8", (long long)pl.units * 2048);
+    PWV_CHECK_ARG(a->ring_stride >= (size_t)pl.units * 2048 && a->ring_stride % 4 == 0,
+                  "pwv_wavenet_stack_persist_f32: ring_stride smaller than one tile32 buffer (%lld floats)", (long long)pl.units * 2048);
     p.ring_stride = (long long)a->ring_stride;
     p.packed_stride = (long long)a->packed_layer_stride;
     p.proj_row_stride = a->proj_row_stride;
@@ -1074,7 +966,6 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
         for (int g = 1; g < a->G; ++g)
             PWV_CHECK_ARG((p.fold0[g] == nullptr) == (p.fold0[0] == nullptr), "pwv_wavenet_stack_persist_f32: first_fold must be set for all nets or for none");
     }
-    p.cond = a->cond;
     p.trace = nullptr;
 #ifdef PWV_PTRACE
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }
@@ -1083,15 +974,10 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     const size_t n16 = align256((size_t)a->G * pl.nwg * kProgStride * 4 + 16) / 16;
     if (!a->workspace_clean)
         hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
-    const dim3 grid(a->G * pl.nwg), block(512);
     if (a->precision == PWV_PREC_F32)
-        hipLaunchKernelGGL((stack_persist_kernel<kArF32, false>), grid, block, 0, s, p);
-    else if (a->precision == PWV_PREC_F16X3)
-        hipLaunchKernelGGL((stack_persist_kernel<kArF16x3, false>), grid, block, 0, s, p);
-    else if (a->cond)
-        hipLaunchKernelGGL((stack_persist_kernel<kArH16, true>), grid, block, 0, s, p);
+        hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
     else
-        hipLaunchKernelGGL((stack_persist_kernel<kArH16, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL(stack_persist_kernel<false>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "persistent stack kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;

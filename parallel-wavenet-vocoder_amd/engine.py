@@ -59,7 +59,8 @@ FOLD_FIRST = os.environ.get('PWV_FOLD_FIRST', '1') != '0'
 # launch per layer.  PWV_PERSIST = 0 | 1 | auto (default: wherever the library supports the shape; '1' forces it).
 _pm = os.environ.get('PWV_PERSIST', 'auto')
 PERSIST = {'0': False, '1': True}.get(_pm, 'auto')
-PERSIST_AUTO_MAX_ROWS = 1 << 30
+PERSIST_AUTO_MAX_ROWS = 600000     # rows (N*T) per launch up to which 'auto' takes the persistent launch: measured on C3's model (round 4, same box,
+                                   # per-layer vs persistent): 160000 rows -5.5 %, 320000 -3.5 %, 480000 -0.6 %, 640000 +0.3 %, 960000 +1.5 % per step
 PERSIST_MIN_UNITS = 0         # short inputs: fewer workgroups rather than ranges below this many units (0 = the library's default, 4)
 PERSIST_MAX_LAYERS = 32       # longest run of layers in one persistent launch (a stack is cut into equal runs that hand the ring on)
 # PWV_ASYNC=1: the reference-shaped calls (IAFVocoder / WaveNet / LinearIAFLayer __call__) only ENQUEUE, like the C ABI; the
@@ -168,7 +169,7 @@ def _persist_runs(L: int, first: int = 1) -> List[Tuple[int, int]]:
     return runs
 
 
-def _use_persist(G: int, n: int, t: int, dilations, first: int = 1, prec: int = _lib.PREC_F16X3) -> bool:
+def _use_persist(G: int, n: int, t: int, dilations, first: int = 1) -> bool:
     L = len(dilations)
     if PERSIST is False or L < 4:
         return False
@@ -180,7 +181,6 @@ def _use_persist(G: int, n: int, t: int, dilations, first: int = 1, prec: int = 
         pa.G, pa.n_layers, pa.N, pa.T = G, cnt, n, t
         pa.dilations = (ctypes.c_int * cnt)(*[int(d) for d in dilations[j0:j0 + cnt]])
         pa.min_units_per_workgroup = PERSIST_MIN_UNITS
-        pa.precision = prec
         if lib.pwv_persist_workspace_bytes(ctypes.byref(pa)) == 0:
             return False
     return True
@@ -521,18 +521,14 @@ def _same_structure(a, b) -> bool:
             and a.condition_channels == b.condition_channels and a.filter_width == b.filter_width)
 
 
-def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec, cond_t=None):
-    """The layers 0 .. L-2 of a stack as ONE persistent launch (layer 0 rebuilt from the flow's scalar input inside it; in the
-    fp16 mode, or without a scalar input, layer 0 is a launch of its own in front), then layer L-1 with the head behind it (one
-    launch); all nets of the flow in every launch, all on the current stream.  `bufs[g]` holds THREE tile32 buffers: the
-    persistent launch rotates through them (include/pwv_hip.h, pwv_persist_args.x_ring).  `cond_t`: per-sample condition in
-    the form the fp16 mode reads (the only arithmetic whose persistent launch takes one)."""
+def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec):
+    """Layer 0 (one launch), layers 1 .. L-2 (ONE persistent launch), layer L-1 with the head behind it (one launch); all
+    nets of the flow in every launch, all on the current stream.  `bufs[g]` holds THREE tile32 buffers: the persistent
+    launch rotates through them (include/pwv_hip.h, pwv_persist_args.x_ring)."""
     G, L = len(nets), plans[0].n_layers
     net0 = nets[0]
     hop, offset, frames = cond_geom
     stride = plans[0].layer_floats
-    half = prec == _lib.PREC_F16
-    first_inside = x_first is not None and not half      # the run starts with the net's layer 0
 
     def layer_args(j, src, dst):
         la = _lib.LayerArgs()
@@ -546,26 +542,16 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         la.N, la.T, la.dilation = n, t, int(net0.dilations[j])
         la.cond_hop, la.cond_offset, la.cond_frames = hop, offset, frames
         la.precision = prec
-        if cond_t is not None:
-            la.cond, la.cond_channels = cond_t.data_ptr(), net0.condition_channels
         return la
 
-    if not first_inside:
-        # layer 0 as a launch of its own: on the causal layer's buffer (bufs[g][0]), or rebuilding it from the scalar input
+    if x_first is None:                     # layer 0 on the causal layer's buffer (bufs[g][0]) as a launch of its own
         la = layer_args(0, 0, 2)
         la.out_mode = _lib.OUT_RESIDUAL
-        if x_first is not None:
-            la.x_first, la.x_limit, la.range_flag = _ptr(x_first), x_limit, range_flag_ptr()
-            for g in range(G):
-                la.causal_filter[g] = plans[g].causal_filter.data_ptr()
-            if FOLD_FIRST and all(p.first_fold is not None for p in plans):
-                for g in range(G):
-                    la.first_fold[g] = plans[g].first_fold.data_ptr()
         check(lib.pwv_wavenet_layer_f32(ctypes.byref(la), s), 'pwv_wavenet_layer_f32')
 
     # the residual layers (0 or) 1 .. L-2 as persistent launches of at most PERSIST_MAX_LAYERS layers each, handing the ring on
     rot, out_slot = 0, 2
-    for j0, cnt in _persist_runs(L, 0 if first_inside else 1):
+    for j0, cnt in _persist_runs(L, 1 if x_first is None else 0):
         pa = _lib.PersistArgs()
         pa.G, pa.n_layers = G, cnt
         dil = (ctypes.c_int * cnt)(*[int(d) for d in net0.dilations[j0:j0 + cnt]])
@@ -589,8 +575,6 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         pa.N, pa.T = n, t
         pa.precision = prec
         pa.cond_hop, pa.cond_offset, pa.cond_frames = hop, offset, frames
-        if cond_t is not None:
-            pa.cond, pa.cond_channels = cond_t.data_ptr(), net0.condition_channels
         nbytes = lib.pwv_persist_workspace_bytes(ctypes.byref(pa))
         if nbytes == 0:
             raise _lib.PwvError('pwv_persist_workspace_bytes: %s' % lib.pwv_last_error().decode())
@@ -607,14 +591,14 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
         if ev is not None:
             ev[1].record()
-            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt, 1 if (j0 == 0 and first_inside) else 0))
+            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt, 1 if j0 == 0 else 0))
         out_slot = (cnt - 1 + rot) % 3      # where this run left its last layer
         rot = (out_slot + 1) % 3            # the next run's input buffer is (2 + rot') % 3 == out_slot
     spare = (out_slot + 1) % 3
 
     la = layer_args(L - 1, out_slot, spare)
     la.out_mode = _lib.OUT_GATED
-    fuse_head = prec == _lib.PREC_F16X3 or FUSE_HEAD
+    fuse_head = prec == _lib.PREC_F16X3 or (prec == _lib.PREC_F32 and FUSE_HEAD)
     if fuse_head:                        # the head runs inside the last layer's launch
         for g in range(G):
             la.head_packed[g] = plans[g].packed_head.data_ptr()
@@ -772,13 +756,8 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # front buffer is neither written nor read
     first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32, _lib.PREC_F16) and qin == 1 and net0.filter_width == 2
                    and net0.residual_channels == 64 and not net0.use_skip_connection and plans[0].causal_bias is None)
-    # the persistent stack launch: fp32 / split-fp16 without a per-sample condition; the fp16 mode with or without one (two
-    # layers WITH their condition weights fit its LDS).  The fp16 run starts behind layer 0.
-    if half:
-        persist = (not use_skip and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations, 1, prec))
-    else:
-        persist = ((prec == _lib.PREC_F32 or FUSE_HEAD) and mode != 'samples' and not use_skip
-                   and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1, prec))
+    persist = ((prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
+               and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1))
     two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
     row_stride = 128 * L
@@ -805,7 +784,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     # ---- causal layer (modules.py:174-183) ----------------------------------------------------
     R = net0.residual_channels
     if persist:      # the persistent launch rotates through three buffers of one allocation (pwv_persist_args.x_ring)
-        bufs = [list(torch.empty((3, lib.pwv_tile32_floats(rows, R)), dtype=torch.float16 if half else torch.float32, device=dev).unbind(0)) for _ in nets]
+        bufs = [list(torch.empty((3, lib.pwv_tile32_floats(rows, R)), dtype=torch.float32, device=dev).unbind(0)) for _ in nets]
     else:
         bufs = [[tile_buf(R, torch.float16 if half else torch.float32) for _ in range(2)] for _ in nets]
     # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
@@ -838,8 +817,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
 
     if persist:
         _run_stack_persist(lib, nets, plans, projs, bufs, outs, x if first_fused else None, x_limit, row_stride,
-                           (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec,
-                           cond_t if mode == 'samples' else None)
+                           (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec)
         return outs
     if two:
         for g in range(2):

@@ -77,50 +77,6 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
     assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 1)      # it really was persistent
 
 
-@pytest.mark.parametrize('n,t,L,G,cond,min_units,max_layers', [
-    (1, 160000, 10, 2, 'frames', 0, 32), (1, 16000, 10, 2, 'samples', 0, 32), (3, 2400, 6, 1, 'none', 0, 32),
-    (2, 24000, 30, 2, 'samples', 2, 32),      # two units per workgroup over 30 layers, two utterances, per-sample condition
-    (1, 16000, 12, 1, 'frames', 1, 32),       # one unit per workgroup
-    (1, 48000, 13, 2, 'samples', 0, 4),       # runs of 4 + 4 + 3 layers: every ring rotation
-    (1, 96, 5, 2, 'samples', 0, 32)])         # three units in all
-def test_fp16_mode_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G, cond, min_units, max_layers):
-    """Round 4: the fp16 storage mode (BASELINE config 5) inside the persistent launch -- WITH the per-sample condition of the
-    transposed-conv upsampling (models.py:109-124), whose weights fit the LDS next to two layers' `hi` halves in this mode only.
-    Layer 0 stays a launch of its own in front (its FIRST / FOLD form), the last layer + head one behind; the layers 1 .. L-2
-    run the per-layer kernel's unit body, so the bits are the per-layer path's."""
-    import torch
-    engine = persist_knobs
-    store, nets = _nets(gpu, L, G, cond_channels=None if cond == 'none' else 80)
-    g = torch.Generator().manual_seed(n * 13 + L)
-    x = torch.randn((n, t, 1), generator=g).to(gpu)
-    if cond == 'frames':
-        c = engine.RepeatedCondition(torch.rand((n, t // 80 + 1, 80), generator=g).to(gpu), 80, 40, t)
-    elif cond == 'samples':
-        c = (torch.rand((n, t, 80), generator=g) * 2 - 1).to(gpu)
-    else:
-        c = None
-    engine.run_nets(nets, x, c, precision='f16')  # creates the variables
-    for name in list(store.vars):
-        if store.vars[name].dim() == 1:
-            store.vars[name].normal_(0, 0.1)
-    store.version += 1
-    engine.PERSIST = False
-    ref = [o.clone() for o in engine.run_nets(nets, x, c, precision='f16')]
-    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS = True, min_units, max_layers
-    log = engine.EVENT_LOG = []
-    try:
-        for _ in range(3):
-            got = engine.run_nets(nets, x, c, precision='f16')
-            torch.cuda.synchronize()
-            assert engine.persist_status() == 0
-            for a, b in zip(ref, got):
-                assert torch.equal(a, b)
-    finally:
-        engine.EVENT_LOG = None
-    runs = engine._persist_runs(L, 1)       # (the fp16 run starts behind layer 0)
-    assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 2)
-
-
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('n,t,L,G,cond', [(1, 16000, 10, 2, 'frames'), (3, 2400, 6, 1, 'frames'), (2, 4000, 5, 2, 'none'), (1, 1234, 3, 2, 'samples')])
 def test_folded_layer0_is_the_same_function_on_every_path(gpu, persist_knobs, n, t, L, G, cond, precision):
