@@ -201,9 +201,9 @@ def attach_profile(roof, args, rows):
     roof['traffic'] = tj['traffic_bytes_per_launch']
     roof['traffic_over_algorithmic'] = tj['ratio']
     roof['traffic_source'] = os.path.relpath(tpath, ROOT)
-    if 'rocprof_kernel_us' in tj:
+    if 'frac_rocprof' in tj:
         roof['rocprof_kernel_us'] = tj['rocprof_kernel_us']
-        roof['frac_rocprof'] = tj['algorithmic_bytes_per_launch'] / (tj['rocprof_kernel_us'] * 1e-6) / 1e9 / PEAK_HBM_GBS
+        roof['frac_rocprof'] = tj['frac_rocprof']      # (concurrent launches x) algorithmic bytes per launch / the rocprofv3 average / 8 TB/s
 
 
 def main():

@@ -64,9 +64,13 @@ for name, label in (('c3', 'C3 default model 1 x 160000 (headline)'), ('c4', 'C4
     if persist:
         fwd = nf / float(roof['launches_per_forward'])
         alg = fwd * roof['alg_bytes_per_forward']
+        units = fwd * roof['net_layers_per_forward'] * ((rows + 31) // 32)
+        conc = 1.0
     else:
         fwd = None
         alg = nf * roof['alg_bytes_per_launch']      # (per-layer launches: the bench line's figure is per launch; the PMC runs are the same launches)
+        units = nf * ((rows + 31) // 32)      # one net per launch on its own stream
+        conc = float(roof.get('concurrent_launches', 1.0))      # launches of this kernel sharing the chip (two chains on two streams), measured by bench.py
     tj = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --no-cpu-baseline --no-f32-exact --no-graph --steps 2 --warmup 1 '
                      + ' '.join(['--case', b['config']['case']] + (['--precision', b['precision']] if b['precision'] != 'f16x3' else [])),
           'workload': b['config']['workload'], 'rows': rows, 'kernel_pattern': pat,
@@ -79,19 +83,21 @@ for name, label in (('c3', 'C3 default model 1 x 160000 (headline)'), ('c4', 'C4
         for r in csv.DictReader(open(st)):
             if pat in r['Name']:
                 tj['rocprof_kernel_us'], tj['rocprof_kernel_calls'] = float(r['AverageNs']) / 1e3, int(r['Calls'])
-                tj['frac_rocprof'] = tj['algorithmic_bytes_per_launch'] / (tj['rocprof_kernel_us'] * 1e-6) / PEAK
-                tj['frac_rocprof_note'] = 'algorithmic bytes per launch / rocprofv3 --stats average launch duration / 8 TB/s'
+                tj['concurrent_launches'] = conc
+                tj['frac_rocprof'] = conc * tj['algorithmic_bytes_per_launch'] / (tj['rocprof_kernel_us'] * 1e-6) / PEAK
+                tj['frac_rocprof_note'] = ('concurrent_launches x algorithmic bytes per launch / rocprofv3 --stats average launch duration / 8 TB/s '
+                                           '(concurrent_launches: the bench line\'s measured overlap of the two chains\' launches; 1 for the persistent launch)')
                 break
     json.dump(tj, open(os.path.join(out, '%s_%s_hbm_traffic.json' % (tag, name)), 'w'), indent=1)
     simds = 1024.0 if persist else 512.0
     rows_md.append((label, b['value'] / 1e6, b['ms_per_step'], b['model']['hbm_frac_of_8TBs'], roof['kernel'].split(' (')[0], roof['frac'],
                     tj.get('frac_rocprof', float('nan')), traffic / alg, busy / (act / 8.0 * simds) if act else float('nan'),
-                    valu / mfma * 120 if mfma else float('nan')))
+                    valu / units, mfma / units))
 print('# per-configuration table (tools/profile_round4.sh, %s): bench line + rocprofv3 stats + PMC passes of the same build on one box\n' % tag)
-print('| config (one MI355X) | M samples/s | ms/step | whole model, frac of 8 TB/s | dominant kernel | its frac of 8 TB/s, HIP events (bench `roofline.frac`) | same from the rocprofv3 --stats average | HBM traffic / algorithmic bytes | matrix pipe busy | VALU per 120 MFMA |')
+print('| config (one MI355X) | M samples/s | ms/step | whole model, frac of 8 TB/s | dominant kernel | its frac of 8 TB/s, HIP events (bench `roofline.frac`) | same from the rocprofv3 --stats average | HBM traffic / algorithmic bytes | matrix pipe busy | VALU / MFMA instructions per 32-row unit |')
 print('|---|---|---|---|---|---|---|---|---|---|')
 for r in rows_md:
-    print('| %s | %.1f | %.3f | %.3f | `%s` | %.3f | %.3f | %.2f | %.0f %% | %.0f |' % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], 100 * r[8], r[9]))
+    print('| %s | %.1f | %.3f | %.3f | `%s` | %.3f | %.3f | %.2f | %.0f %% | %.0f / %.0f |' % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], 100 * r[8], r[9], r[10]))
 pl = bench('c3_perlayer')
 if pl:
     print('\nC3 with the per-layer launches (PWV_PERSIST=0), same box: %.1f M samples/s, %.3f ms/step, whole model %.3f of 8 TB/s.'
@@ -99,5 +105,6 @@ if pl:
 print('\nTraffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B summed over the dominant kernel\'s launches of an eager 2-step run (gfx950 counts 128-byte read '
       'requests at 64 B: MI355X_MICROARCH.md, HBM).  Algorithmic bytes of the same launches = forwards x `roofline.alg_bytes_per_forward` of the bench line '
       '(512 B per sample, net and layer; 260 B for a net\'s layer 0 folded onto its scalars; + the per-sample condition in transposed-conv mode).  Matrix pipe busy = '
-      'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x SIMDs the launch occupies) -- GRBM_GUI_ACTIVE is summed over the 8 XCDs.  The per-configuration '
+      'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x SIMDs the launch occupies) -- GRBM_GUI_ACTIVE is summed over the 8 XCDs; instructions per unit = '
+      'SQ_INSTS_VALU / SQ_INSTS_MFMA over the units those launches ran (a persistent launch averages its folded layer 0: 36 MFMAs, with the others: 120).  The per-configuration '
       'raw totals are in %s_<cfg>_hbm_traffic.json (what bench.py reads for `roofline.traffic` / `frac_rocprof`).' % tag)
