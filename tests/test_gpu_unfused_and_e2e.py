@@ -305,6 +305,51 @@ def test_graphed_vocoder_matches_eager_bitwise(gpu):
         graphed(mel[:, :-1])
 
 
+def test_graphed_vocoder_recaptures_when_the_engine_switches_launch_paths(gpu):
+    """A captured graph holds the launches of the path the engine was on.  After a persistent give-up the engine is on per-layer
+    launches: GraphedVocoder.verify() raises like IAFVocoder.verify() AND re-captures, so the caller's rerun replays launches that
+    can complete; a switch made behind its back (engine.PERSIST set by another model's verified call) is noticed at the next
+    replay.  (The give-up word is poked from the host: a real one needs a second process on the GPU.)"""
+    import ctypes
+    import torch
+    from pwv_amd import engine
+    from pwv_amd._lib import PwvPersistError
+    from pwv_amd.graph import GraphedVocoder
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    cfg = O.ModelConfig(dilations=[[1, 2, 4, 8, 16, 32], [1, 2, 4, 8, 16, 32]], n_iaf=2)
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=2))
+    n, length = 1, 16000
+    mel_np, z_np = O.synthetic_inputs(n, length, cfg)
+    mel, z = torch.from_numpy(mel_np).to(gpu), torch.from_numpy(z_np).to(gpu)
+    model = IAFVocoder(batch_size=n, length=length, store=store)
+    saved = engine.PERSIST
+    try:
+        engine.PERSIST = False
+        want = model(None, mel, is_training=False, z=z).clone()
+        engine.PERSIST = True
+        graphed = GraphedVocoder(model)
+        captured = graphed.graph
+        assert torch.equal(graphed(mel, z=z), want)
+        graphed.verify()
+        engine.persist_status()
+        ctypes.c_int.from_address(engine._persist_status_addr).value = 4
+        with pytest.raises(PwvPersistError):
+            graphed.verify()
+        assert engine.PERSIST is False and graphed.graph is not captured      # re-captured on the per-layer path
+        assert torch.equal(graphed(mel, z=z), want)
+        graphed.verify()
+        # ... and a switch it was not told about: noticed at the next replay
+        recaptured = graphed.graph
+        engine.PERSIST = True
+        assert torch.equal(graphed(mel, z=z), want) and graphed.graph is not recaptured
+        graphed.verify()
+    finally:
+        engine.PERSIST = saved
+
+
 def test_bench_multi_rank_control_flow_on_one_gpu():
     """bench.py for N > 1, both ways it can be started -- under torch.distributed.run (one process per rank) and plainly
     (`python bench.py --gpus 2`: it then spawns its ranks itself) -- with the test hook PWV_BENCH_DRYRUN_ONE_GPU=1: both

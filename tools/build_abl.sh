@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds timing-only variants of the library for the A/B runs of tools/ab.sh:
-#   tools/build_abl.sh ABL_NOXB16
+#   tools/build_abl.sh ABL_NOXB16 ABL_BLOCK
 # Each NAME becomes tools/abl_so/libpwv_NAME.so, compiled with -DPWV_NAME from a scratch copy of csrc/ with
 # tools/probes/persist_probes.patch applied (the probes are kept out of the product sources).  Results are WRONG by design
 # for the ABL_* variants; only the step time is of interest.  (Rounds 1-2 used perturb.patch against the per-layer kernel
