@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 import weakref
 from ctypes import c_void_p
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -96,7 +97,7 @@ def raise_if_persist_failed() -> None:
                                    'is used from now on, rerun the forward' % code)
 
 
-_verify_depth = 0         # > 0 inside a reference-shaped call that owns the verification of everything it enqueues
+_verify = threading.local()      # .depth > 0 inside a reference-shaped call that owns the verification of everything it enqueues (per thread)
 
 
 def clear_persist_status() -> None:
@@ -123,16 +124,17 @@ def verified_call(run, verify: Optional[bool] = None):
     So `pred = model(wav, mel, is_training=False); pred.cpu()` (generate.py:38,68) yields a correct result or an exception,
     never inf from a silent fp16 overflow.  verify=False (or PWV_ASYNC=1, or a call under stream capture, or a call nested in
     another reference-shaped call) only enqueues; the caller then owns verify_enqueued() / IAFVocoder.verify()."""
-    global _verify_depth, PERSIST
+    global PERSIST
     if verify is None:
         verify = not ASYNC
-    if _verify_depth > 0 or not verify or torch.cuda.is_current_stream_capturing():
-        _verify_depth += 1
+    depth = getattr(_verify, 'depth', 0)
+    if depth > 0 or not verify or torch.cuda.is_current_stream_capturing():
+        _verify.depth = depth + 1
         try:
             return run(None)
         finally:
-            _verify_depth -= 1
-    _verify_depth += 1
+            _verify.depth = depth
+    _verify.depth = 1
     try:
         out = run(None)
         torch.cuda.current_stream().synchronize()
@@ -151,7 +153,7 @@ def verified_call(run, verify: Optional[bool] = None):
             raise_if_range_flag("its rerun in precision 'f32'")
         return out
     finally:
-        _verify_depth -= 1
+        _verify.depth = 0
 
 
 def _persist_runs(L: int, first: int = 1) -> List[Tuple[int, int]]:
