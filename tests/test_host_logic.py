@@ -192,3 +192,46 @@ def test_bench_time_sharded_mode_is_strong_scaling():
     assert 'time-sharded x2' in out['config']['parallelism'] and '6160 samples' in out['config']['parallelism']
     assert 'cut into 2 time shards' in out['sharded_generate']
     assert abs(out['value'] * out['ms_per_step'] * 1e-3 - 960000) < 1.0          # the job's samples, counted once per step
+
+
+@pytest.mark.parametrize('case,precision,name', [('bench/c3', 'f16x3', 'c3'), ('bench/c4', 'f16x3', 'c4'), ('bench/c5', 'f16x3', 'c5'), ('bench/c5', 'f16', 'c5_f16')])
+def test_roofline_reproduces_from_the_committed_profiles(case, precision, name):
+    """bench.py's `roofline.traffic` / `frac_rocprof` come from profiles/rNN_x_<case>_hbm_traffic.json of the SAME configuration; that
+    file in turn follows from raw counter totals, the rocprofv3 average and the bench line of the same set by plain arithmetic
+    (tools/profile_round4_summarize.py) -- checked here, so a hand edit or a stale file cannot go unnoticed."""
+    import glob
+    import json
+    import types
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tpath = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_*_%s_hbm_traffic.json' % name)))[-1]
+    tj = json.load(open(tpath))
+    bline = [l for l in open(tpath.replace('_hbm_traffic.json', '_bench.json')) if l.startswith('{')][-1]
+    b = json.loads(bline)
+    roof_b = b['roofline']
+    rows = b['config']['utterances_per_gpu'] * b['config']['samples_per_utterance']
+    assert tj['rows'] == rows and b['config']['case'] == case and b['precision'] == precision
+    # raw counters -> traffic (gfx950: FETCH_SIZE counts 128-byte requests at 64 B)
+    assert abs(tj['traffic_bytes_total'] - (2 * tj['FETCH_SIZE_KB_total'] + tj['WRITE_SIZE_KB_total']) * 1024.0) < 1.0
+    # the bench line's own per-forward / per-launch figures -> algorithmic bytes of the same launches
+    if 'alg_bytes_per_forward' in roof_b:
+        layer_bytes = roof_b['alg_bytes_per_net_layer'] // rows
+        assert roof_b['alg_bytes_per_forward'] == rows * (roof_b['net_layers_per_forward'] * layer_bytes
+                                                            - roof_b['first_net_layers_per_forward'] * (layer_bytes // 2 - 4))
+        assert tj['algorithmic_bytes_total'] == tj['forwards'] * roof_b['alg_bytes_per_forward']
+        assert tj['launches'] == tj['forwards'] * roof_b['launches_per_forward']
+    else:
+        assert tj['algorithmic_bytes_total'] == tj['launches'] * roof_b['alg_bytes_per_launch']
+    assert abs(tj['ratio'] - tj['traffic_bytes_total'] / tj['algorithmic_bytes_total']) < 1e-12
+    assert abs(tj['traffic_bytes_per_launch'] - tj['traffic_bytes_total'] / tj['launches']) < 1e-3
+    frac = tj['concurrent_launches'] * tj['algorithmic_bytes_per_launch'] / (tj['rocprof_kernel_us'] * 1e-6) / 8.0e12
+    assert abs(tj['frac_rocprof'] - frac) < 1e-12
+    # ... and the kernel-stats table of the set holds that average
+    stats = open(tpath.replace('_hbm_traffic.json', '_kernel_stats.md')).read()
+    assert ('| %.2f |' % tj['rocprof_kernel_us']) in stats
+    # what bench.py attaches for this --case
+    roof = {'kernel': roof_b['kernel']}
+    bench.attach_profile(roof, types.SimpleNamespace(case=case, precision=precision), rows)
+    assert roof['traffic'] == tj['traffic_bytes_per_launch'] and roof['frac_rocprof'] == tj['frac_rocprof']
+    assert roof['traffic_source'].startswith('profiles/')
+    assert abs(roof['frac_rocprof'] - roof_b['frac']) < 0.08 * roof_b['frac']      # the profiler costs a few per cent, not more
