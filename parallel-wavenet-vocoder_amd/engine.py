@@ -142,11 +142,17 @@ def verified_call(run, verify: Optional[bool] = None):
             clear_persist_status()
             clear_range_flag()          # (whatever consumed the invalid rows may have raised it)
             PERSIST = False
+            import warnings
+            warnings.warn('pwv: a persistent stack launch gave up (its workgroups were not all resident -- another process on this GPU?); '
+                          'the forward is rerun on per-layer launches (same arithmetic, same bits) and the process stays on them')
             out = run(None)
             torch.cuda.current_stream().synchronize()
             raise_if_persist_failed()
         if range_flag_raised():
             clear_range_flag()
+            import warnings
+            warnings.warn("pwv: an input or activation left the exponent range of the split-fp16 arithmetic; the forward is rerun in exact fp32 "
+                          "(precision='f32', the reference's arithmetic) on the same noise")
             out = run('f32')
             torch.cuda.current_stream().synchronize()
             raise_if_persist_failed()

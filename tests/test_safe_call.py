@@ -56,7 +56,8 @@ def test_give_up_inside_the_call_is_rerun_on_per_layer_launches(stub_engine):
         if len(runs) == 1:
             state['persist'], state['range'] = 4, True      # the give-up, and garbage downstream tripping the range guard
         return 'y%d' % len(runs)
-    assert engine.verified_call(run) == 'y2'
+    with pytest.warns(UserWarning, match='rerun on per-layer launches'):
+        assert engine.verified_call(run) == 'y2'
     assert runs == [(None, 'auto'), (None, False)] and engine.PERSIST is False and not state['range']
 
 
@@ -69,7 +70,9 @@ def test_range_flag_inside_the_call_is_rerun_in_f32(stub_engine):
         if prec is None:
             state['range'] = True
         return prec
-    assert engine.verified_call(run) == 'f32' and runs == [None, 'f32'] and log == ['sync', 'sync']
+    with pytest.warns(UserWarning, match='rerun in exact fp32'):
+        assert engine.verified_call(run) == 'f32'
+    assert runs == [None, 'f32'] and log == ['sync', 'sync']
 
 
 def test_a_rerun_that_still_fails_raises(stub_engine):
@@ -79,7 +82,7 @@ def test_a_rerun_that_still_fails_raises(stub_engine):
     def run(prec):
         state['range'] = True          # e.g. a NaN in the input: no arithmetic repairs that
         return prec
-    with pytest.raises(PwvRangeError):
+    with pytest.raises(PwvRangeError), pytest.warns(UserWarning):
         engine.verified_call(run)
 
 
@@ -97,7 +100,8 @@ def test_nested_async_and_opted_out_calls_only_enqueue(stub_engine):
     assert engine.verified_call(lambda p: 'raw', verify=False) == 'raw' and log == [] and state['range']
     engine.ASYNC = True
     assert engine.verified_call(lambda p: 'raw') == 'raw' and log == []
-    assert engine.verified_call(lambda p: p, verify=True) == 'f32'      # an explicit verify=True wins over PWV_ASYNC
+    with pytest.warns(UserWarning):
+        assert engine.verified_call(lambda p: p, verify=True) == 'f32'      # an explicit verify=True wins over PWV_ASYNC
 
 
 # ---- on the device ----------------------------------------------------------------------------------------------------
@@ -123,7 +127,8 @@ def test_reference_shaped_call_never_returns_inf(gpu, method):
     mel_t = torch.from_numpy((mel * 1e5).astype(np.float32)).to(gpu)
     model, store = _model(gpu, cfg, length, n)
     model.noise_seed = 77
-    pred = model(None, mel_t, is_training=False)
+    with pytest.warns(UserWarning, match='rerun in exact fp32'):      # (the repair is not silent)
+        pred = model(None, mel_t, is_training=False)
     got = pred.cpu()
     assert bool(torch.isfinite(got).all())
     assert not engine.range_flag_raised() and engine.persist_status() == 0      # nothing left behind for the next caller
@@ -178,7 +183,8 @@ def test_give_up_inside_a_call_is_repaired_inside_the_call(gpu, monkeypatch):
                 poked.append(1)
                 ctypes.c_int.from_address(engine._persist_status_addr).value = 4
         monkeypatch.setattr(engine, '_run_stack_persist', spy)
-        got = model(None, mel_t, is_training=False, z=z_t)
+        with pytest.warns(UserWarning, match='per-layer launches'):
+            got = model(None, mel_t, is_training=False, z=z_t)
         assert poked and engine.PERSIST is False and engine.persist_status() == 0
         assert torch.equal(got, want)
     finally:
@@ -198,7 +204,9 @@ def test_wavenet_and_iaf_layer_called_directly_are_safe_too(gpu):
         sc, sh = WaveNet(name='scalar', **kw), WaveNet(name='shifter', **kw)
         sc32, sh32 = WaveNet(name='scalar', precision='f32', **kw), WaveNet(name='shifter', precision='f32', **kw)
     x = (torch.randn((1, 640, 1), generator=torch.Generator().manual_seed(3)) * 3e5).to(gpu)
-    y = sc(x)
+    with pytest.warns(UserWarning, match='exact fp32'):
+        y = sc(x)
     assert bool(torch.isfinite(y).all()) and torch.equal(y, sc32(x))
-    out = LinearIAFLayer(1, sc, sh)(x)
+    with pytest.warns(UserWarning, match='exact fp32'):
+        out = LinearIAFLayer(1, sc, sh)(x)
     assert bool(torch.isfinite(out).all()) and torch.equal(out, LinearIAFLayer(1, sc32, sh32)(x))
