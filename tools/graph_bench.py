@@ -39,7 +39,7 @@ def timeit(fn, iters=30):
 y_eager = model(None, mel, is_training=False, z=z).clone()
 graphed = GraphedVocoder(model)
 y_graph = graphed(mel, z=z).clone()
-t_e = timeit(lambda: model(None, mel, is_training=False, z=z))
+t_e = timeit(lambda: model(None, mel, is_training=False, z=z, verify=False))      # enqueue-only: the timed loop must not synchronise
 t_g = timeit(lambda: graphed(mel, z=z))
 print('%s: %d x %d samples | eager %.3f ms (%.1f M samples/s) | graph %.3f ms (%.1f M samples/s) | bit-identical: %s' % (
     case, n, length, t_e, n * length / t_e / 1e3, t_g, n * length / t_g / 1e3, torch.equal(y_eager, y_graph)))
