@@ -67,7 +67,8 @@ PERSIST_MAX_LAYERS = 32       # longest run of layers in one persistent launch (
 # PWV_ASYNC=1: the reference-shaped calls (IAFVocoder / WaveNet / LinearIAFLayer __call__) only ENQUEUE, like the C ABI; the
 # caller then owns IAFVocoder.verify() / engine.verify_enqueued().  Default: a call returns only after its own launches
 # have completed and the library's sticky words (range guard, persistent give-up) are clean -- or it has rerun itself on
-# the path that is (per-layer launches / exact fp32).  bench.py, graph.py and generate() opt out per call (verify=False).
+# the path that is (per-layer launches / exact fp32).  bench.py and graph.py opt out per call (verify=False) and verify for
+# themselves; generate() passes verify=True, which outranks this knob: nothing unverified is ever written to disk.
 ASYNC = os.environ.get('PWV_ASYNC', '0') == '1'
 _persist_status_addr = None
 _persist_ws = {}          # (device, stream) -> zeroed workspace of the persistent launches on that stream

@@ -147,8 +147,9 @@ def generate(case='default', ckpt=None, debug=False):
         e0.record()
     # feed forward (generate.py:68).  The call returns a verified result: a persistent launch that gave up is rerun on per-layer
     # launches, a forward that left the range of the split-fp16 arithmetic in exact fp32 -- on the same noise
-    # (engine.verified_call); what comes back is what the reference's fp32 sess.run would have produced, or an exception
-    pred = model(gt_wav, melspec, is_training=False)
+    # (engine.verified_call); what comes back is what the reference's fp32 sess.run would have produced, or an exception.
+    # verify=True is EXPLICIT: it outranks PWV_ASYNC=1 (whose default is enqueue-only) -- nothing unverified is written to disk
+    pred = model(gt_wav, melspec, is_training=False, verify=True)
     if ckpt:
         # tf.train.Saver.restore fails on a variable the checkpoint lacks (generate.py:59-63); here variables are
         # created lazily by the forward, so the coverage check comes after it
@@ -210,21 +211,34 @@ def _generate_over_ranks(store, batch_size, length, device, logdir, ckpt, debug)
     errors = []
 
     def make_model(n, window):
-        m = IAFVocoder(batch_size=n, length=window, store=store)
+        # A failure anywhere in this rank's share -- the constructor (length not a multiple of the hop), the forward, its
+        # verification -- must not leave the other ranks alone in the gather: hand back zeros, keep the collectives paired,
+        # and let the failure bit below stop every rank before anything is written
+        try:
+            m = IAFVocoder(batch_size=n, length=window, store=store)
+        except Exception as e:
+            errors.append(e)
+            m = None
 
         def run(mel, z):
-            # a verified call: this rank's share is complete and checked (rerun on per-layer launches / in exact fp32 if need
-            # be) BEFORE it is gathered.  A failure must not leave the other ranks alone in the gather: hand back zeros, keep
-            # the collectives paired, and let the failure bit below stop every rank before anything is written
+            # a verified call (explicitly: verify=True outranks PWV_ASYNC=1): this rank's share is complete and checked --
+            # rerun on per-layer launches / in exact fp32 if need be -- BEFORE it is gathered
             try:
-                return m(None, mel, is_training=False, z=z)
+                if m is None:
+                    raise errors[0]
+                return m(None, mel, is_training=False, z=z, verify=True)
             except Exception as e:
-                errors.append(e)
+                if not errors or errors[-1] is not e:
+                    errors.append(e)
                 return torch.zeros((mel.shape[0], window, 1), dtype=torch.float32, device=device)
         return run
 
     def noise_window(n, first_sample, window, first_item):
-        return engine.logistic_noise_window(n, length, first_sample, window, device, seed, first_item)
+        try:
+            return engine.logistic_noise_window(n, length, first_sample, window, device, seed, first_item)
+        except Exception as e:
+            errors.append(e)
+            return torch.zeros((n, window, 1), dtype=torch.float32, device=device)
 
     # a normaliser that reduces over time (modules.py:274-284) makes a time slice depend on the whole utterance: such a model
     # shards by utterance only (ranks beyond the batch idle) -- timeshard.py is exact for causal FIR structure, nothing else
