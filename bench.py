@@ -23,8 +23,9 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                    (pwv_stack_args.ev_begin / ev_end, production launch path) against 8 TB/s; `traffic` = HBM bytes per
                    launch from the committed PMC passes (profiles/); the matrix-pipe view is beside it as roofline_mfma
                    (with --precision f32 the roles swap: fp32 MFMA roofline, HBM view beside it)
-  cpu_baseline  -- the oracle's torch-CPU fp32 port of the same model timed on this host's cores
-                   on a bounded sample (rank 0, N=1 only); a reported baseline, not the target.
+  cpu_baseline  -- the oracle's torch-CPU fp32 port of the same model timed on this host's cores on a bounded sample
+                   (rank 0, N=1 only), cache-blocked in time and swept over {1, 2, 4, 8, 16, 32, physical cores} workers:
+                   `value_1thread`, `value_best` (= `value`), `threads_swept`; a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -79,6 +80,7 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
     ap.add_argument('--no-f32-exact', action='store_true', help="skip the second timing of the same workload in exact fp32 ('f32_exact')")
+    ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)      # (internal: the cpu_baseline leg in a clean process)
     return ap.parse_args()
 
 
@@ -95,44 +97,93 @@ def spawn_ranks(n):
     return subprocess.call(cmd)
 
 
-def cpu_baseline(case_cfg, target_s):
-    """Oracle port (torch-CPU fp32 restatement of modules.py:11-259 / models.py:23-136) timed on
-    the host cores on a bounded sample of the same model.  oneDNN's small-channel convolutions do not
-    scale to every core of a big host, so a short probe picks the best of a few thread counts first."""
-    import torch
-    from oracle import iaf_oracle as O
-    from oracle.torch_cpu import iaf_vocoder_forward_torch
-    w = O.init_weights(case_cfg, seed=2)
-    hop = case_cfg.hop_length
-    probe = 50 * hop
-    mel, z = O.synthetic_inputs(1, probe, case_cfg)
-    max_threads = torch.get_num_threads()
-    best = (0.0, max_threads)
-    for cores in sorted({max_threads, max(1, max_threads // 2), min(max_threads, 32), min(max_threads, 16)}, reverse=True):
-        torch.set_num_threads(cores)
-        iaf_vocoder_forward_torch(w, mel, z, case_cfg)           # warm-up (oneDNN primitive caches)
-        t0 = time.perf_counter()
-        iaf_vocoder_forward_torch(w, mel, z, case_cfg)
-        rate = probe / (time.perf_counter() - t0)
-        if rate > best[0]:
-            best = (rate, cores)
-    rate, cores = best
-    torch.set_num_threads(cores)
-    length = int(min(160000, max(probe, rate * target_s)) // hop * hop)
-    mel, z = O.synthetic_inputs(1, length, case_cfg)
-    t0 = time.perf_counter()
-    iaf_vocoder_forward_torch(w, mel, z, case_cfg)
-    dt = time.perf_counter() - t0
-    torch.set_num_threads(max_threads)
-    cpu_model = 'unknown CPU'
+def physical_cores():
+    """Physical cores of this host (lscpu-style: distinct (package, core) pairs of /proc/cpuinfo; SMT siblings counted once)."""
     try:
+        pairs, phys, core = set(), None, None
         with open('/proc/cpuinfo') as f:
-            cpu_model = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':', 1)[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':', 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if pairs:
+            return min(len(pairs), os.cpu_count() or len(pairs))
     except Exception:
         pass
-    return {'value': length / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': 'same model, 1 utterance x %d samples (%.1f s CPU), torch-CPU fp32 restatement (oracle/torch_cpu.py), '
-                      'best of {%d, %d, 32, 16} threads = %d on %s' % (length, dt, max_threads, max_threads // 2, cores, cpu_model)}
+    return os.cpu_count() or 1
+
+
+def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process'):
+    """Oracle port (torch-CPU fp32 restatement of modules.py:11-259 / models.py:23-136) timed on the host cores on a bounded
+    sample of the same model (k = 1 and k = all physical cores; generate.py:47-50 is the reference's own
+    CPU / GPU switch).  Evaluated flow by flow in time chunks of `chunk` samples with each flow's look-back recomputed
+    (oracle/torch_cpu.py ChunkedForward: the same function; a chunk's working set stays in cache instead of streaming 41 MB
+    tensors through DRAM) and with one chunk per core at a time (k workers x single-threaded ops) instead of every small conv
+    split over all cores -- the form in which this math scales on a many-core host.  Sweep {1, 2, 4, 8, 16, 32, physical cores}
+    on 2k chunks each (constant time per point), then the best k on a sample sized to `target_s` seconds."""
+    from oracle import iaf_oracle as O
+    from oracle.torch_cpu import ChunkedForward
+    w = O.init_weights(case_cfg, seed=2)
+    hop = case_cfg.hop_length
+    chunk = max(hop, chunk // hop * hop)
+    logical, phys = os.cpu_count() or 1, physical_cores()
+    sweep = sorted({k for k in (1, 2, 4, 8, 16, 32, phys) if k <= logical})
+    rates, fwd = {}, {}
+    for k in sweep:
+        f = fwd[k] = ChunkedForward(w, case_cfg, chunk, k, mode)
+        mel, z = O.synthetic_inputs(1, chunk * 2 * k, case_cfg)
+        t0 = time.perf_counter()
+        f(mel, z)
+        rates[k] = chunk * 2 * k / (time.perf_counter() - t0)
+        if k != 1:
+            f.close()
+    best = max(rates, key=lambda k: rates[k])
+    fwd[1].close()
+    n_chunks = int(max(best, min(160000 // chunk, rates[best] * target_s // chunk)))
+    n_chunks = max(best, n_chunks // best * best)                  # whole rounds of `best` chunks
+    length = n_chunks * chunk
+    f = ChunkedForward(w, case_cfg, chunk, best, mode)
+    mel, z = O.synthetic_inputs(1, length, case_cfg)
+    t0 = time.perf_counter()
+    y = f(mel, z)
+    dt = time.perf_counter() - t0
+    f.close()
+    assert np.isfinite(y).all()
+    cpu_model = 'unknown CPU'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            cpu_model = next(l.split(':', 1)[1].strip() for l in fh if l.startswith('model name'))
+    except Exception:
+        pass
+    return {'value': length / dt, 'unit': 'samples/s', 'cores': best, 'kind': 'port',
+            'value_1thread': rates[1], 'value_best': length / dt, 'threads_swept': {str(k): round(v, 1) for k, v in rates.items()},
+            'physical_cores': phys, 'logical_cpus': logical, 'cpu': cpu_model, 'chunk_samples': chunk, 'workers': mode,
+            'sample': 'same model, 1 utterance x %d samples (%.1f s wall on %d cores), torch-CPU fp32 restatement of the reference math '
+                      '(oracle/torch_cpu.py, conditioning per sample as written) evaluated in %d-sample time chunks with the flow\'s look-back '
+                      'recomputed, one chunk per core at a time (%s pool); sweep on 2k chunks for k in %s, best = %d; value_1thread is the k = 1 point'
+                      % (length, dt, best, chunk, mode, sorted(rates), best)}
+
+
+def cpu_baseline(case, case_cfg, target_s):
+    """The measurement above in a CLEAN child process (no HIP runtime, no OpenMP team: its fork()ed worker pool is safe there and
+    free of the GIL); if the child cannot be had, the same measurement in this process on a thread pool."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--case', case, '--cpu-seconds', str(target_s)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=max(180.0, 12 * target_s),
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES='', OMP_NUM_THREADS='1'))
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        sys.stderr.write('cpu_baseline child failed (rc %d): %s\n' % (r.returncode, r.stderr[-400:]))
+    except Exception as e:
+        sys.stderr.write('cpu_baseline child failed (%s: %s)\n' % (type(e).__name__, e))
+    return cpu_baseline_measure(case_cfg, target_s, mode='thread')
 
 
 def model_algorithmic_work(hp, elem_bytes):
@@ -186,10 +237,11 @@ def latest_profile_json(suffix):
 
 
 def attach_profile(roof, args, rows):
-    """`traffic` (HBM bytes per launch from the PMC passes) and the rocprofv3-timed launch duration of the dominant kernel, from
-    the committed profile set of THIS configuration (profiles/rNN_x_<case>[_<precision>]_hbm_traffic.json, written by
-    tools/profile_round4_summarize.py from the same command under rocprofv3) -- with the roofline fraction recomputed from
-    that duration next to the live, event-timed one."""
+    """`traffic` (HBM bytes per launch from the PMC passes) and the rocprofv3-timed launch duration of the dominant kernel come
+    from the COMMITTED profile set of this configuration (profiles/rNN_x_<case>[_<precision>]_hbm_traffic.json, written by
+    tools/profile_round4_summarize.py from the same command under rocprofv3 on the builder's box) -- PMC passes cannot run inside
+    the timed region.  Everything that is not measured by THIS run sits under `committed_profile` and says so
+    (`measured_in_run: false`); `traffic` itself, which the contract wants in the roofline object, is tagged the same way."""
     name = args.case.replace('bench/', '') + ('' if args.precision == 'f16x3' else '_' + args.precision)
     tpath = latest_profile_json('_%s_hbm_traffic.json' % name)
     if not tpath:
@@ -199,15 +251,25 @@ def attach_profile(roof, args, rows):
     if tj.get('rows') != rows or tj.get('kernel_pattern', '').split('<')[0] not in roof['kernel']:
         return
     roof['traffic'] = tj['traffic_bytes_per_launch']
-    roof['traffic_over_algorithmic'] = tj['ratio']
-    roof['traffic_source'] = os.path.relpath(tpath, ROOT)
+    roof['traffic_measured_in_run'] = False
+    cp = {'measured_in_run': False, 'source': os.path.relpath(tpath, ROOT),
+          'box': tj.get('box', "the builder's gpurun box of that profile round (one MI355X), not the box of this run"),
+          'command': tj.get('command'), 'traffic_bytes_per_launch': tj['traffic_bytes_per_launch'],
+          'algorithmic_bytes_per_launch': tj.get('algorithmic_bytes_per_launch'), 'traffic_over_algorithmic': tj['ratio']}
     if 'frac_rocprof' in tj:
-        roof['rocprof_kernel_us'] = tj['rocprof_kernel_us']
-        roof['frac_rocprof'] = tj['frac_rocprof']      # (concurrent launches x) algorithmic bytes per launch / the rocprofv3 average / 8 TB/s
+        cp['rocprof_kernel_us'] = tj['rocprof_kernel_us']
+        cp['frac_rocprof'] = tj['frac_rocprof']      # (concurrent launches x) algorithmic bytes per launch / the rocprofv3 average / 8 TB/s
+    roof['committed_profile'] = cp
 
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_child:
+        from oracle.iaf_oracle import ModelConfig
+        from pwv_amd.hparam import hparam as hp_
+        hp_.set_hparam_yaml(args.case)
+        print(json.dumps(cpu_baseline_measure(ModelConfig.from_hparam(hp_), args.cpu_seconds, mode='process')))
+        return
     # PWV_BENCH_DRYRUN=control (test hook, tests/test_host_logic.py): no GPU work at all -- the launcher / rendezvous / barrier /
     # max-over-ranks / rank-0 JSON control flow with a no-op step, over gloo on CPU.
     # PWV_BENCH_DRYRUN_ONE_GPU=1 (test hook, tests/test_gpu_unfused_and_e2e.py): the real step, but all ranks share GPU 0 and
@@ -249,7 +311,15 @@ def main():
         # ("RCCL version : ..." at NCCL_DEBUG >= VERSION) and NCCL WARN lines (seen on the GPU box: "alt_rsmi.cc NCCL WARN Could
         # not read node # 9" at init AND at teardown, glued to whatever was printed last).  Leave NCCL_DEBUG as the caller set it
         # (unset = silent) and send the stream to stderr; the JSON line is printed after the process group is gone (below).
-        os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
+        # (Only when stderr is a tty / pipe: RCCL opens the file for writing, which would truncate a regular file that `2> log`
+        # points at and clobber what the ranks wrote before -- there the JSON line printed last is the protection.)
+        try:
+            import stat
+            stderr_is_file = stat.S_ISREG(os.fstat(2).st_mode)
+        except OSError:
+            stderr_is_file = True
+        if not stderr_is_file:
+            os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = 'gloo' if dryrun else 'nccl'                              # 'nccl' IS RCCL on ROCm (xGMI)
@@ -410,8 +480,28 @@ def main():
         f32_exact = (e32, n32, graphed32)
         del step32, out32
 
-    # ---- utterance scatter / gather over the job's backend, once, outside the timed loop (N > 1) --------------------
-    sharded = None
+    # ---- the JOB as north_star words it, over the job's backend (N > 1, or PWV_BENCH_FORCE_DIST=1): all mels on rank 0 -> scatter
+    # (utterance shards) / broadcast of slices (time shards) -> every rank's verified forward -> gather of the waveforms on rank 0.
+    # One untimed call, then the median of 5 timed ones, each between barriers -- `job.job_samples_per_s` next to the weak-scaling
+    # `value` (whose timed loop is forward-only: every rank on its own resident mel)
+    sharded, job = None, None
+    JOB_CALLS = 5
+
+    def timed_job(call):
+        call()                                   # (untimed: model objects for the shard shapes, plans, RCCL channels)
+        times = []
+        for _ in range(JOB_CALLS):
+            sync_all()
+            t0 = time.perf_counter()
+            w_ = call()
+            sync_all()
+            times.append(time.perf_counter() - t0)
+        if dist is not None:
+            t = torch.tensor(times, dtype=torch.float64, device='cpu' if dryrun else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times = [float(v) for v in t.tolist()]
+        return w_, sorted(times)[len(times) // 2], times
+
     if dist is not None and time_shard is not None:
         from pwv_amd.distributed import generate_time_sharded_ranks
         coll_dev = torch.device('cpu') if dryrun else dev
@@ -420,16 +510,22 @@ def main():
         if control:
             fwd = lambda m, zz, t0: torch.zeros((m.shape[0], (m.shape[1] - 1) * hop, 1))
         else:
+            nets_by_window = {}
+
             def fwd(m, zz, t0):
                 win = (m.shape[1] - 1) * hop
-                net = model0 if win == length else IAFVocoder(batch_size=m.shape[0], length=win, store=store, precision=args.precision)
+                if win not in nets_by_window:
+                    nets_by_window[win] = model0 if win == length else IAFVocoder(batch_size=m.shape[0], length=win, store=store, precision=args.precision)
                 zw = engine.logistic_noise_window(m.shape[0], job_length, t0, win, dev, 4242)
-                return net(None, m.to(dev), is_training=False, z=zw).to(coll_dev)      # (a verified call: rerun inside if a sticky word is raised)
-        wav = generate_time_sharded_ranks(fwd, full_mel, n_mels, job_length, hop, time_shard['halo'], coll_dev)
+                return nets_by_window[win](None, m.to(dev), is_training=False, z=zw, verify=True).to(coll_dev)      # (a verified call: rerun inside if a sticky word is raised)
+        wav, job_s, job_times = timed_job(lambda: generate_time_sharded_ranks(fwd, full_mel, n_mels, job_length, hop, time_shard['halo'], coll_dev))
+        job_samples = utts * job_length
         if rank == 0:
             assert tuple(wav.shape) == (utts, job_length, 1) and bool(torch.isfinite(wav).all())
             sharded = '%d utterance(s) x %d samples cut into %d time shards (look-back %d samples), generated, gathered on rank 0: ok' % (
                 utts, job_length, time_shard['shards'], time_shard['halo'])
+            job = {'what': 'distributed.generate_time_sharded_ranks: mel on rank 0 -> slices to the ranks -> verified forward per rank -> waveform gathered on rank 0',
+                   'samples': job_samples}
     elif dist is not None:
         from pwv_amd.distributed import generate_sharded
         total = utts * world
@@ -438,13 +534,24 @@ def main():
         if control:
             fwd = lambda m, zz: torch.zeros((m.shape[0], length, 1))
         else:
+            nets_by_batch = {}
+
             def fwd(m, zz):
-                net = model0 if m.shape[0] == utts else IAFVocoder(batch_size=m.shape[0], length=length, store=store, precision=args.precision)
-                return net(None, m.to(dev), is_training=False, z=zz).to(coll_dev)      # (a verified call)
-        wav = generate_sharded(fwd, full_mel, (t_mel, n_mels), length, coll_dev)
+                nb = m.shape[0]
+                if nb not in nets_by_batch:
+                    nets_by_batch[nb] = model0 if nb == utts else IAFVocoder(batch_size=nb, length=length, store=store, precision=args.precision)
+                return nets_by_batch[nb](None, m.to(dev), is_training=False, z=zz, verify=True).to(coll_dev)      # (a verified call)
+        wav, job_s, job_times = timed_job(lambda: generate_sharded(fwd, full_mel, (t_mel, n_mels), length, coll_dev))
+        job_samples = total * length
         if rank == 0:
             assert tuple(wav.shape) == (total, length, 1) and bool(torch.isfinite(wav).all())
             sharded = '%d utterances scattered over %d ranks, generated, gathered on rank 0: ok' % (total, world)
+            job = {'what': 'distributed.generate_sharded: all mels on rank 0 -> scatter -> verified forward per rank (noise sampled on the device) -> waveforms gathered on rank 0',
+                   'samples': job_samples}
+    if job is not None:
+        job.update({'job_samples_per_s': job_samples / job_s, 'job_ms_median': job_s * 1e3, 'job_ms_all': [round(v * 1e3, 4) for v in job_times],
+                    'calls': JOB_CALLS, 'launch': 'host-enqueued, verified calls (each waits for its launches and reads the sticky words); max over ranks per call',
+                    'note': 'the job-level number: inputs start and results end on rank 0; `value` above is the forward-only weak-scaling metric of SURVEY.md section 8d'})
 
     # ---- live kernel timing of the dominant kernel (HIP events on the launch streams) --------------------------------
     timing = None
@@ -531,6 +638,7 @@ def main():
             result['rccl_ranks'] = world if backend == 'nccl' else 0
             result['backend'] = backend
             result['sharded_generate'] = sharded
+            result['job'] = job
         if control:
             result['dryrun'] = 'control flow only: no kernels ran, value is meaningless (PWV_BENCH_DRYRUN=control)'
         mb, mf = model_algorithmic_work(hp, 2 if args.precision == 'f16' else 4)
@@ -642,7 +750,7 @@ def main():
                 'launch': 'HIP graph replay' if g32 else 'host-enqueued launches'}
         if n_gpus == 1 and not args.no_cpu_baseline and not control:
             from oracle.iaf_oracle import ModelConfig          # the oracle is only ever the CPU leg, never the timed path
-            result['cpu_baseline'] = cpu_baseline(ModelConfig.from_hparam(hp), args.cpu_seconds)
+            result['cpu_baseline'] = cpu_baseline(args.case, ModelConfig.from_hparam(hp), args.cpu_seconds)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

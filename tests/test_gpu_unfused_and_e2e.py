@@ -403,6 +403,9 @@ def test_bench_takes_every_rccl_branch_at_world_size_one(extra, want):
     j = json.loads(lines[0])
     assert j['n_gpus'] == 1 and j['rccl_ranks'] == 1 and j['backend'] == 'nccl' and j['value'] > 0
     assert want in j['sharded_generate'] and j['sharded_generate'].endswith('ok')
+    # ... and the job-level number next to the forward-only `value`: rank 0's inputs -> RCCL scatter -> verified forward -> gather
+    job = j['job']
+    assert job['calls'] == 5 and job['job_samples_per_s'] > 0 and job['job_samples_per_s'] < 1.05 * j['value']
 
 
 def test_device_mel_frontend_matches_numpy_restatement(gpu):

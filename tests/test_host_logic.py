@@ -171,6 +171,10 @@ def test_bench_spawns_its_own_ranks_when_started_without_a_launcher():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
     assert 'scattered over 2 ranks' in out['sharded_generate'] and 'dryrun' in out
+    # the job-level number (rank 0's mels -> scatter -> forward -> gather): median of 5 calls, max over ranks per call
+    job = out['job']
+    assert job['calls'] == 5 and len(job['job_ms_all']) == 5 and job['samples'] == 2 * 160000
+    assert abs(job['job_samples_per_s'] * job['job_ms_median'] * 1e-3 - job['samples']) < 1.0
 
 
 def test_bench_time_sharded_mode_is_strong_scaling():
@@ -191,12 +195,13 @@ def test_bench_time_sharded_mode_is_strong_scaling():
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong'
     assert 'time-sharded x2' in out['config']['parallelism'] and '6160 samples' in out['config']['parallelism']
     assert 'cut into 2 time shards' in out['sharded_generate']
+    assert out['job']['samples'] == 960000 and 'generate_time_sharded_ranks' in out['job']['what'] and out['job']['job_samples_per_s'] > 0
     assert abs(out['value'] * out['ms_per_step'] * 1e-3 - 960000) < 1.0          # the job's samples, counted once per step
 
 
 @pytest.mark.parametrize('case,precision,name', [('bench/c3', 'f16x3', 'c3'), ('bench/c4', 'f16x3', 'c4'), ('bench/c5', 'f16x3', 'c5'), ('bench/c5', 'f16', 'c5_f16')])
 def test_roofline_reproduces_from_the_committed_profiles(case, precision, name):
-    """bench.py's `roofline.traffic` / `frac_rocprof` come from profiles/rNN_x_<case>_hbm_traffic.json of the SAME configuration; that
+    """bench.py's `roofline.traffic` / `committed_profile.frac_rocprof` come from profiles/rNN_x_<case>_hbm_traffic.json of the SAME configuration; that
     file in turn follows from raw counter totals, the rocprofv3 average and the bench line of the same set by plain arithmetic
     (tools/profile_round4_summarize.py) -- checked here, so a hand edit or a stale file cannot go unnoticed."""
     import glob
@@ -232,6 +237,8 @@ def test_roofline_reproduces_from_the_committed_profiles(case, precision, name):
     # what bench.py attaches for this --case
     roof = {'kernel': roof_b['kernel']}
     bench.attach_profile(roof, types.SimpleNamespace(case=case, precision=precision), rows)
-    assert roof['traffic'] == tj['traffic_bytes_per_launch'] and roof['frac_rocprof'] == tj['frac_rocprof']
-    assert roof['traffic_source'].startswith('profiles/')
-    assert abs(roof['frac_rocprof'] - roof_b['frac']) < 0.08 * roof_b['frac']      # the profiler costs a few per cent, not more
+    cp = roof['committed_profile']
+    assert roof['traffic'] == tj['traffic_bytes_per_launch'] and cp['frac_rocprof'] == tj['frac_rocprof']
+    assert roof['traffic_measured_in_run'] is False and cp['measured_in_run'] is False      # (provenance: canned, and labelled so)
+    assert cp['source'].startswith('profiles/') and not any(k in roof for k in ('frac_rocprof', 'rocprof_kernel_us', 'traffic_source'))
+    assert abs(cp['frac_rocprof'] - roof_b['frac']) < 0.08 * roof_b['frac']      # the profiler costs a few per cent, not more

@@ -67,6 +67,22 @@ def test_fp32_roundoff_budget():
     assert np.abs(yt - z['y']).max() < 5e-6      # the timed cpu_baseline port computes the same function
 
 
+@pytest.mark.parametrize('method', ['repeat', 'transposed_conv'])
+def test_chunked_cpu_port_is_the_same_function(method):
+    """bench.py's cpu_baseline evaluates the port flow by flow in time chunks with each flow's look-back recomputed, one chunk
+    per worker (oracle/torch_cpu.py ChunkedForward): the same function as the unchunked port, chunk boundaries off the hop grid
+    and worker pools (threads; fork()ed processes) included."""
+    from oracle.torch_cpu import iaf_vocoder_forward_torch_chunked, flow_halo
+    cfg = O.ModelConfig(dilations=[[1, 2, 4, 8, 16], [1, 2, 4, 8, 16, 32, 64]], n_iaf=2, cond_upsample_method=method)
+    assert flow_halo(O.ModelConfig(), 0) == 1024 and flow_halo(O.ModelConfig(), 3) == 3070      # SURVEY 8c KAT 5: RF - 1
+    w = O.init_weights(cfg, seed=4)
+    mel, z = O.synthetic_inputs(2, 1600, cfg)
+    want = iaf_vocoder_forward_torch(w, mel, z, cfg)
+    for chunk, workers, mode in ((400, 1, 'thread'), (250, 3, 'thread'), (560, 2, 'process')):
+        got = iaf_vocoder_forward_torch_chunked(w, mel, z, cfg, chunk=chunk, workers=workers, mode=mode)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6, (chunk, workers, mode)
+
+
 def _one_net_cfg(**kw):
     base = dict(dilations=[[1, 2, 4, 8]], n_iaf=1)
     base.update(kw)
