@@ -462,8 +462,8 @@ def main():
                 again = int(t.item())
             if not again:
                 return made, elapsed_, out_
-            if not control:
-                engine.PERSIST = False
+            if not control and not engine.persist_suspended():
+                engine.suspend_persist()          # (the give-up was on another rank: this rank leaves the persistent launches with it)
             if attempt:
                 raise failed[0] if failed else _lib.PwvPersistError('a persistent launch gave up on another rank, twice')
             sys.stderr.write('%s\nre-timing with per-layer launches\n' % (failed[0] if failed else 'a persistent launch gave up on another rank'))
@@ -576,6 +576,7 @@ def main():
         #          ('persist', ...) ONE persistent launch covering `cnt` layers of `gnets` nets
         pers = [(ref.elapsed_time(en[1]), ref.elapsed_time(en[2]), en[4], en[3]) for en in log if en[0] == 'persist']
         first_runs = sum(en[3] for en in log if en[0] == 'persist' and len(en) > 5 and en[5])      # net-layers that read 4 B instead of 256 B per sample
+        tail_runs = sum(en[3] for en in log if en[0] == 'persist' and len(en) > 6 and en[6])       # nets whose LAST layer + head ran inside the launch
         chains = [(ref.elapsed_time(en[1]), ref.elapsed_time(en[2]), en[4], en[3]) for en in log if en[0] == 'layer_residual']
         if pers:
             # a forward has a few distinct launches (9- and 29-layer runs); take the MEDIAN duration of each kind over the timed
@@ -587,7 +588,8 @@ def main():
             total_ms = sum(med[(cnt, gnets)] for _, _, cnt, gnets in pers)
             timing = {'kind': 'persist', 'forwards': n_event_fwd, 'launches': len(pers), 'total_ms': total_ms, 'net_layers': sum(cnt * g for _, _, cnt, g in pers),
                       'launch_ms': [min(med.values()), max(med.values())],
-                      'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3], 'first_net_layers': first_runs}
+                      'layers_per_launch': sorted(set(cnt for _, _, cnt, _ in pers)), 'nets_per_launch': pers[0][3], 'first_net_layers': first_runs,
+                      'tail_net_layers': tail_runs}
         elif chains:
             busy = merged_length([(b, e) for b, e, _, _ in chains])
             total_ms = sum(e - b for b, e, _, _ in chains)
@@ -650,13 +652,19 @@ def main():
         if timing is not None and timing['kind'] == 'persist':
             # the dominant kernel is the persistent stack kernel: one launch runs `layers` residual layers of both nets of a flow
             # over all timed launches; a run that starts with the net's layer 0 reads 4 B per sample there instead of a 256 B row
-            alg_bytes = rows * (timing['net_layers'] * layer_bytes - timing['first_net_layers'] * (layer_bytes // 2 - 4))
-            alg_flop = rows * timing['net_layers'] * LAYER_FLOP_PER_SAMPLE
+            # ... and (round 5) the net's LAST layer with the head behind it rides in the same launch: it reads the residual stream once
+            # (half a layer's bytes) and writes Q floats per sample; 2 x (2*64*128 + 64*128 + 128*128 + 128*Q) FLOP per sample
+            q_out = 2 if bool(hp.model.get('shared_nets', False)) else 1
+            tail_bytes = layer_bytes // 2 + 4 * q_out
+            tail_flop = 2 * (2 * 64 * 128 + 64 * 128 + 128 * 128 + 128 * q_out)
+            alg_bytes = rows * (timing['net_layers'] * layer_bytes - timing['first_net_layers'] * (layer_bytes // 2 - 4) + timing['tail_net_layers'] * tail_bytes)
+            alg_flop = rows * (timing['net_layers'] * LAYER_FLOP_PER_SAMPLE + timing['tail_net_layers'] * tail_flop)
             ach_gbs = alg_bytes / (timing['total_ms'] * 1e-3) / 1e9
             ach_tf = alg_flop / (timing['total_ms'] * 1e-3) / 1e12
             arith = {'f16x3': 'split-fp16 MFMA', 'f32': 'exact fp32 MFMA', 'f16': 'fp16 rows + fp16 MFMA'}[args.precision]
-            roof = {'kernel': 'stack_persist_kernel (persistent dataflow launch: %s residual layers x %d nets per launch, %s)'
-                              % ('/'.join(str(c) for c in timing['layers_per_launch']), timing['nets_per_launch'], arith),
+            roof = {'kernel': 'stack_persist_kernel (persistent dataflow launch: %s residual layers%s x %d nets per launch, %s)'
+                              % ('/'.join(str(c) for c in timing['layers_per_launch']),
+                                 ' + last layer + head + IAF affine' if timing['tail_net_layers'] else '', timing['nets_per_launch'], arith),
                     'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS,
                     'launches_timed': timing['launches'], 'launch_ms_median_by_kind': timing['launch_ms'],
                     'us_per_layer_pair': timing['total_ms'] * 1e3 / (timing['net_layers'] / timing['nets_per_launch']),
@@ -664,9 +672,11 @@ def main():
                     # what ONE forward launches of this kernel (tools/profile_round4_summarize.py prices the PMC / rocprof passes with it)
                     'launches_per_forward': timing['launches'] // timing['forwards'], 'net_layers_per_forward': timing['net_layers'] // timing['forwards'],
                     'first_net_layers_per_forward': timing['first_net_layers'] // timing['forwards'],
+                    'tail_net_layers_per_forward': timing['tail_net_layers'] // timing['forwards'], 'alg_bytes_per_tail_net_layer': rows * tail_bytes,
                     'alg_bytes_per_forward': alg_bytes // timing['forwards'],
                     'traffic': None,
-                    'note': 'achieved = algorithmic bytes (512 B per sample, net and layer) of the layers a launch runs / its duration, '
+                    'note': 'achieved = algorithmic bytes of the layers a launch runs (512 B per sample, net and residual layer; 260 B for a folded '
+                            'layer 0; 256 B + 4 Q for the last layer + head when they run inside the launch) / its duration, '
                             'HIP events around each persistent launch on its stream (median per kind of launch over the timed forwards)'}
             attach_profile(roof, args, rows)
             cond_flop = 2 * int(hp.model.condition_channels) * 128 if hp.model.cond_upsample_method == 'transposed_conv' else 0
@@ -686,7 +696,8 @@ def main():
                 folded = engine.FOLD_FIRST and timing['first_net_layers'] > 0
                 first_issued = 3 * 2 * (16 * 128 + 64 * 64) if folded else 3 * LAYER_FLOP_PER_SAMPLE
                 issued_tf = rows * ((timing['net_layers'] - timing['first_net_layers']) * 3 * LAYER_FLOP_PER_SAMPLE
-                                    + timing['first_net_layers'] * first_issued) / (timing['total_ms'] * 1e-3) / 1e12
+                                    + timing['first_net_layers'] * first_issued
+                                    + timing['tail_net_layers'] * 3 * (tail_flop - 2 * 128 * q_out)) / (timing['total_ms'] * 1e-3) / 1e12
                 roof['first_layer'] = 'folded onto its four input scalars (one MFMA k-step for filter|gate)' if folded else 'as every other layer'
                 roof['limiter'] = LIMITER_K1P
                 result['roofline_mfma'] = {'bound': 'mfma', 'achieved': issued_tf, 'peak': PEAK_F16_MFMA_TFLOPS,

@@ -111,6 +111,12 @@ int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, 
  * PWV_PREC_F32 (the Python host raises PwvRangeError / reruns).
  * ------------------------------------------------------------------------------------- */
 int pwv_range_flag(int** flag);
+/* A caller's OWN pair of sticky words in pinned, device-visible host memory (both zero): words[0] for pwv_persist_args.status,
+ * words[1] as the range flag of any entry point that takes one.  One pair per (device, stream) or per thread keeps concurrent
+ * callers apart (the process-wide words above are shared by everybody who does not bring their own).  Free with
+ * pwv_status_words_free when no launch that was handed them can still be running. */
+int pwv_status_words_alloc(int** words);
+int pwv_status_words_free(int* words);
 int pwv_range_check_f32(const float* x, int64_t n, float limit, int* flag, pwv_stream_t stream);
 /* pack-time statistics of one layer (R = D = 64, S = 128; TF layouts) for the host's bound on the residual stream:
  * out8 = max|filter|, max|gate|, max|dense|, max|skip|, max|gc_filter|, max|gc_gate| (0 when NULL),
@@ -421,6 +427,23 @@ typedef struct pwv_persist_args {
      * eight): the same function (h[t] is linear in x[t-1], x[t]), rounded differently -- within the path's tolerance of the
      * unfolded form, not bit-identical to it */
     const float* first_fold[PWV_MAX_NETS];
+    /* optional: this call's own sticky give-up word (pwv_status_words_alloc: words[0]); NULL = the process-wide word of
+     * pwv_persist_status.  Two threads / streams with their own words cannot consume or clear each other's flags. */
+    int* status;
+    /* optional TAIL (PWV_PREC_F16X3, tail_q > 0; the run must be the LAST run of the stack): behind the run's layers every
+     * workgroup runs the net's last layer (dilation tail_dilation, packed weights tail_layer[g], P columns proj[g] + 128*n_layers)
+     * with the post-processing head behind it (tail_head[g] = pwv_pack_head_f32's output; modules.py:145-165) on its own rows and
+     * writes tail_out[g] [N*T, tail_q] -- what pwv_wavenet_layer_f32 with head_packed / head_out computes, bit for bit, without
+     * the two kernel boundaries.  With affine_x (the flow's input [N*T]) the IAF affine out = x*s + b (modules.py:59) is evaluated
+     * too: s = net 0, b = net 1 (G = 2, tail_q = 1; by whichever of the two nets' workgroups of a row range finishes second) or
+     * s, b = the two outputs of one net (G = 1, tail_q = 2); affine_out [N*T].  A flow is then ONE launch. */
+    const float* tail_layer[PWV_MAX_NETS];
+    const float* tail_head[PWV_MAX_NETS];
+    float* tail_out[PWV_MAX_NETS];
+    int tail_q;
+    int tail_dilation;
+    const float* affine_x;
+    float* affine_out;
 } pwv_persist_args;
 
 size_t pwv_persist_workspace_bytes(const pwv_persist_args* args);

@@ -415,6 +415,20 @@ int pwv_range_flag(int** flag) {
     return PWV_OK;
 }
 
+int pwv_status_words_alloc(int** words) {
+    PWV_CHECK_ARG(words, "pwv_status_words_alloc: NULL argument");
+    int* w = nullptr;
+    PWV_CHECK_HIP(hipHostMalloc((void**)&w, 2 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable));
+    w[0] = w[1] = 0;
+    *words = w;
+    return PWV_OK;
+}
+
+int pwv_status_words_free(int* words) {
+    if (words) PWV_CHECK_HIP(hipHostFree(words));
+    return PWV_OK;
+}
+
 int pwv_range_check_f32(const float* x, int64_t n, float limit, int* flag, pwv_stream_t stream) {
     PWV_CHECK_ARG(x && flag && n >= 0, "pwv_range_check_f32: bad arguments");
     if (n == 0) return PWV_OK;

@@ -81,6 +81,15 @@ struct PersistParams {
     float x_limit;                         // range guard of the split-fp16 arithmetic on x_first (include/pwv_hip.h)
     int* range_flag;
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
+    // TAIL (split-fp16 only; tail_q > 0): behind the run's layers every workgroup runs the net's LAST layer with the post-processing
+    // head behind it on its own units (layer_f16x3_kernel's HEAD variant, the same operations) -- and, with `pair`, the IAF affine
+    const float* tail_layer[PWV_MAX_NETS]; // the last layer's packed weights (its filter|gate fragments are used)
+    const float* tail_head[PWV_MAX_NETS];  // the packed head
+    float* tail_out[PWV_MAX_NETS];         // [rows, tail_q]
+    int tail_q, tail_dil, tail_reach_wgs;
+    const float* affine_x;                 // != NULL: out = fma(x, s, b) (modules.py:59) for the workgroup's rows, by whichever of the
+    float* affine_out;                     // two nets' workgroups of a range finishes second (G = 2, Q = 1), or in place (G = 1, Q = 2)
+    int* pair;                             // [nwg] arrival counters of the two nets' workgroups of a range (zero on entry and on exit)
 };
 
 // -DPWV_PTRACE: every wave accumulates s_memtime cycles: [0] whole loop, [1] drain at the top, [2] RAW spins, [3] WAR spins,
@@ -196,6 +205,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     // argument is a scalar LOAD plus a wait each time
     const int v_dil = p.dil[lane & (kMaxPLayers - 1)];
     auto dil_of = [&](int j) -> int { return __builtin_amdgcn_readlane(v_dil, j); };
+    // the layer that reads layer j's rows next: j + 1 of this launch, the tail's layer behind the last one, else (another launch
+    // follows: anything) its own
+    auto dil_next = [&](int j) -> int { return j + 1 < L ? dil_of(j + 1) : (p.tail_q > 0 ? p.tail_dil : dil_of(j)); };
 
     // ---- control state, then the weights of the first two layers (LDS-DMA, packed order == LDS order) -------------------
     for (int k = tid; k < (kLdsFloats - kCtlF); k += 512) ctl[k] = 0;
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const char* F0 = reinterpret_cast<const char*>(p.fold0[net]);
         const float* lastfrag = packed_n + kSlot + lane * 4;
         const int d = dil_of(0);
-        const int dn = dil_of(1 < L ? 1 : 0);
+        const int dn = dil_next(0);
         typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
         const lds_f4_t cfb = (lds_f4_t)(lds + kCfF + 4 * h);
         // the folded fragments and the dense tail are the same for every unit: registers for the whole loop
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             const int so = out_soff(j);
             const int oo = toff(row);
             // units the right neighbour reads as x[t-d] in the next layer are stored write-through
-            const int dn = dil_of(j + 1 < L ? j + 1 : j);
+            const int dn = dil_next(j);
             const bool shared = u + ((dn + 31) >> 5) >= u_end;
             if (valid) {
                 if (shared) {
@@ -808,11 +820,250 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         leave_layers(L);
         if (dma_pending >= 0) flush_owed();
     }
+    // ---- TAIL: the net's LAST layer with the head behind it (modules.py:145-165), then the IAF affine (modules.py:59) -------------
+    // What used to be two more launches per flow (layer_f16x3_kernel<..., HEAD> and the affine) runs here on the workgroup's own
+    // units as soon as ITS eight waves have left the run's last layer -- no grid-wide drain, no launch ramp.  The operations are
+    // those of the HEAD variant in the same order (bit-identical, tests/test_gpu_persist.py).  The head's three matrices take
+    // the whole LDS (filter|gate 64 KB + skip 32 KB + postprocess1 64 KB), so the control state above is gone from here on:
+    // units are handed out statically, the left neighbours' progress words are polled directly, and the exit accounting at
+    // the bottom is done by one thread behind a barrier.
+    bool tail_done = false;
+    if constexpr (!F32) {
+        if (p.tail_q > 0) {
+            tail_done = true;
+            __syncthreads();                       // every wave of the workgroup is out of the task loop (its stores drained, its layers left)
+            const int wg_dead = __builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1]);
+            __syncthreads();                       // ... and has read that word before the weights overwrite it
+            bool tail_ok = !wg_dead;
+            if (tail_ok) {
+                constexpr int kHS = kA1Size, kH1 = kA1Size + kASSize;
+                fill_lds_dma<kA1Size / 4, 8>(lds, p.tail_layer[net] + kA1, wave, lane);
+                fill_lds_dma<kASSize / 4, 8>(lds + kHS, p.tail_head[net] + kHAS, wave, lane);
+                fill_lds_dma<kHA1Size / 4, 8>(lds + kH1, p.tail_head[net] + kHA1, wave, lane);
+                // the look-back of this wave's first unit (u_begin + wave) reaches into the left neighbours iff wave < reach: they must
+                // have completed the run's last layer ("layers completed for all my units" == L), bounded like every other wait
+                const int td = p.tail_dil;
+                if (w > 0 && wave < ((td + 31) >> 5)) {
+                    const int w0 = w - p.tail_reach_wgs > 0 ? w - p.tail_reach_wgs : 0;
+                    const int cnt = w - w0;
+                    const long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (int k = 0;; ++k) {
+                        int v = 1 << 20;
+                        if (lane < cnt) v = __hip_atomic_load(prog_n + (size_t)(w0 + lane) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__ballot(v < L) == 0) break;
+                        if ((k & 63) == 63 && (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
+                                               __builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks)) {
+                            __hip_atomic_store(p.status, 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            tail_ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                   // the head's weights are resident
+                const f16x8* A1 = reinterpret_cast<const f16x8*>(lds);
+                const f16x8* HS = reinterpret_cast<const f16x8*>(lds + kHS);
+                const f16x8* H1 = reinterpret_cast<const f16x8*>(lds + kH1);
+                const float* hb = p.tail_head[net];
+                const int Q = p.tail_q;
+                const int so = in_soff(L);         // the run's last layer wrote buffer (L - 1 + rot) % 3
+                const __amdgpu_buffer_rsrc_t out_rs = [&]() {
+                    const unsigned long long a = (unsigned long long)p.tail_out[net];
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+                    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0,
+                                                             __builtin_amdgcn_readfirstlane((unsigned)rows * (unsigned)Q * 4u), 0x00020000);
+                }();
+                auto load_tail = [&](int unit, float (&xb)[32], float (&xc)[32]) {
+                    int row, rc, nn, t;
+                    bool valid;
+                    unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+                    const bool has_prev = t >= td;
+                    const int oc = toff(rc), ob = toff(has_prev ? rc - td : rc);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, oc + g * 1024, so, 16));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xc[4 * g + e] = v[e];
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, ob + g * 1024, so, 16));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xb[4 * g + e] = has_prev ? v[e] : 0.f;
+                    }
+                };
+                auto no_extra = [](int) {};
+                int unit = u_begin + wave;
+                float txb[32], txc[32];
+                load_tail(unit, txb, txc);      // (unconditional, like every load of rows here: clamped addresses, and registers that are
+                                                // written on every path do not stay live across the GEMMs)
+                while (tail_ok && unit < u_end) {
+                    // (compiler barrier: the head's small vectors -- skip / postprocess1 biases, postprocess2 -- are read from global
+                    // memory per unit like P; hoisted out of the loop they are 192 loop-invariant registers, i.e. spills)
+                    asm volatile("" ::: "memory");
+                    const int next = unit + 8;
+                    int row, rc, nn, t;
+                    bool valid;
+                    unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+                    f32x16 acc[4];
+                    {
+                        int prow = 0;
+                        if (p.cond_hop > 0) prow = nn * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
+                        const float* pr = proj_n + (size_t)prow * p.proj_row_stride + L * 128 + h * 64;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(pr + it * 16 + q * 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
+                            }
+                    }
+                    f16x8 bh[8], bl[8];
+                    float xc[32];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) xc[i] = txc[i];
+                    split8<0>(txb, bh[0], bl[0]);
+                    split8<8>(txb, bh[1], bl[1]);
+                    split8<16>(txb, bh[2], bl[2]);
+                    split8<24>(txb, bh[3], bl[3]);
+                    auto bxh = [&](int s) -> f16x8 { return bh[s]; };
+                    auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+                    float o[32];
+                    f16x8 oh[4], ol[4];
+                    f16x8 ah[4], al[4];
+                    first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
+                    gemm16<8, 2, 0, 2, 4>(
+                        A1, lane, acc, ah, al, bxh, bxl,
+                        [&](int s) {
+                            if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
+                            if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
+                            if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
+                            if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+                        },
+                        [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
+                    gemm16<8, 2, 1, 2, 4>(
+                        A1, lane, acc, ah, al, bxh, bxl,
+                        [&](int s) {
+                            o[2 * s] = gate_act(acc[0][2 * s], acc[2][2 * s]);
+                            o[2 * s + 1] = gate_act(acc[0][2 * s + 1], acc[2][2 * s + 1]);
+                            asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
+                            if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
+                            if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
+                        },
+                        [](f16x8(&)[4], f16x8(&)[4]) {});
+                    // ---- head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2 ---------------------------
+                    f32x16 accs[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHBS + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+                    split8<16>(o, oh[2], ol[2]);
+                    split8<24>(o, oh[3], ol[3]);
+                    first_frags<4, 4, 0, 1, 4>(HS, lane, ah, al);
+                    gemm16<4, 4, 0, 1, 4>(HS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; }, no_extra,
+                                          [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 4, 0, 1, 4>(H1, lane, nh, nl); });
+                    f32x16 acc1[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHB1 + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = v[e];
+                        }
+                    f16x8 sh[8], sl[8];
+                    {
+                        float r[64];
+#pragma unroll
+                        for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
+                        split8<0>(r, sh[0], sl[0]);
+                        split8<8>(r, sh[1], sl[1]);
+                        split8<16>(r, sh[2], sl[2]);
+                        split8<24>(r, sh[3], sl[3]);
+                        split8<32>(r, sh[4], sl[4]);
+                        split8<40>(r, sh[5], sl[5]);
+                        split8<48>(r, sh[6], sl[6]);
+                        split8<56>(r, sh[7], sl[7]);
+                    }
+                    gemm16<8, 4, 0, 1, 4>(H1, lane, acc1, ah, al, [&](int s) -> f16x8 { return sh[s]; }, [&](int s) -> f16x8 { return sl[s]; }, no_extra,
+                                          [](f16x8(&)[4], f16x8(&)[4]) {});
+                    load_tail(next, txb, txc);      // the next unit's rows: in flight under the postprocess2 dot
+                    float outv[kMaxQ] = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = 0; q < Q; ++q) {
+                        float part = 0.f;
+                        const float* w2 = hb + kHW2 + (h * Q + q) * 64;
+#pragma unroll
+                        for (int i4 = 0; i4 < 16; ++i4) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(w2 + 4 * i4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = 4 * i4 + e;
+                                part = fmaf(fmaxf(acc1[i >> 4][i & 15], 0.f), wv[e], part);
+                            }
+                        }
+                        part += __shfl_xor(part, 32);
+                        part += hb[kHW2 + 2 * Q * 64 + q];
+                        if (q < kMaxQ) outv[q] = part;
+                        // (write-through: with `pair` the other net's workgroup of this range may be the one that reads it)
+                        if (valid && h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part), out_rs, (row * Q + q) * 4, 0, kAuxWriteThrough);
+                    }
+                    if (p.affine_x && p.G == 1 && Q == 2) {      // one net with two outputs (scale, shift): the affine right here
+                        if (valid && h == 0) p.affine_out[row] = fmaf(p.affine_x[row], outv[0], outv[1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    unit = next;
+                }
+            }
+            // ---- the IAF affine for this range, by whichever of the two nets' workgroups arrives second ---------------------------
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's outputs are written through
+            __syncthreads();
+            if (p.affine_x && p.pair && p.G == 2) {
+                if (tid == 0) {
+                    const int old = __hip_atomic_fetch_add(p.pair + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(__attribute__((address_space(3))) volatile int*)&ctl[0] = old;
+                }
+                __syncthreads();
+                const int old = __builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[0]);
+                if (old == 1) {
+                    const int r_end = u_end * 32 < rows ? u_end * 32 : rows;
+                    for (int row = u_begin * 32 + tid; row < r_end; row += 512) {
+                        const float sv = __hip_atomic_load(p.tail_out[0] + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float bv = __hip_atomic_load(p.tail_out[1] + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        p.affine_out[row] = fmaf(p.affine_x[row], sv, bv);
+                    }
+                    if (tid == 0) __hip_atomic_store(p.pair + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // exit accounting (below) without the LDS counter: one thread, behind the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave == 0) {
+                int done = 0;
+                if (lane == 0) done = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(done) == p.active_wgs - 1) {
+                    for (int k = lane; k < p.G * p.nwg; k += 64) __hip_atomic_store(p.prog + (size_t)k * kProgStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) {
+                        __hip_atomic_store(p.abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+    }
     // The launch cleans up after itself: the LAST workgroup to finish zeroes every word a later launch polls (progress, abort,
     // this counter), so a launch that is handed this workspace again needs no zeroing kernel in front of it.  A wave counts
     // itself out only when its own global stores are complete (vmcnt(0)): no progress word can land after the zeroing.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
+    if (!tail_done) {
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__builtin_amdgcn_readfirstlane(old) == 7) {
@@ -904,7 +1155,8 @@ size_t pwv_persist_workspace_bytes(const pwv_persist_args* a) {
     const int cus = device_cus();
     if (!a) { set_error(PWV_EINVAL, "pwv_persist_workspace_bytes: NULL argument"); return 0; }
     if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl) != PWV_OK) return 0;
-    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256);      // progress words + the abort word + the exit counter
+    // progress words + the abort word + the exit counter (one 256-byte line) + one arrival counter per range (the tail's affine)
+    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256) + align256((size_t)pl.nwg * 4);
 }
 
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream) {
@@ -923,6 +1175,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     p.prog = (int*)a->workspace;
     p.abort = p.prog + (size_t)a->G * pl.nwg * kProgStride;
     p.exited = p.abort + 1;
+    int* const pair_words = (int*)((char*)a->workspace + align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256));
     p.active_wgs = a->G * (pl.last_wg + 1);
     for (int g = 0; g < a->G; ++g) {
         PWV_CHECK_ARG(a->x_ring[g] && a->packed_layers[g] && a->proj[g], "pwv_wavenet_stack_persist_f32: NULL buffer for net %d", g);
@@ -930,7 +1183,8 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
         p.packed[g] = a->packed_layers[g];
         p.proj[g] = a->proj[g];
     }
-    PWV_CHECK_HIP(pwv_persist_status(&p.status) == PWV_OK ? hipSuccess : hipErrorUnknown);
+    if (a->status) p.status = a->status;      // the caller's own sticky word (pwv_status_words_alloc): concurrent callers stay apart
+    else PWV_CHECK_HIP(pwv_persist_status(&p.status) == PWV_OK ? hipSuccess : hipErrorUnknown);
     PWV_CHECK_ARG(a->ring_stride >= (size_t)pl.units * 2048 && a->ring_stride % 4 == 0,
                   "pwv_wavenet_stack_persist_f32: ring_stride smaller than one tile32 buffer (%lld floats)", (long long)pl.units * 2048);
     p.ring_stride = (long long)a->ring_stride;
@@ -966,12 +1220,41 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
         for (int g = 1; g < a->G; ++g)
             PWV_CHECK_ARG((p.fold0[g] == nullptr) == (p.fold0[0] == nullptr), "pwv_wavenet_stack_persist_f32: first_fold must be set for all nets or for none");
     }
+    // the tail: last layer + head (+ affine) behind the run's layers
+    p.tail_q = 0;
+    if (a->tail_q > 0) {
+        PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3, "pwv_wavenet_stack_persist_f32: the tail (last layer + head inside the launch) exists for PWV_PREC_F16X3 only");
+        PWV_CHECK_ARG(a->tail_q <= kMaxQ && a->tail_dilation >= 1, "pwv_wavenet_stack_persist_f32: tail_q 1..%d, tail_dilation >= 1", kMaxQ);
+        PWV_CHECK_ARG((long long)a->N * a->T * a->tail_q * 4 < (1ll << 32), "pwv_wavenet_stack_persist_f32: tail_out beyond the 4 GB reach of a buffer descriptor");
+        for (int g = 0; g < a->G; ++g) {
+            PWV_CHECK_ARG(a->tail_layer[g] && a->tail_head[g] && a->tail_out[g], "pwv_wavenet_stack_persist_f32: NULL tail buffer for net %d", g);
+            p.tail_layer[g] = a->tail_layer[g];
+            p.tail_head[g] = a->tail_head[g];
+            p.tail_out[g] = a->tail_out[g];
+        }
+        p.tail_q = a->tail_q;
+        p.tail_dil = a->tail_dilation;
+        const int reach = (a->tail_dilation + 31) / 32;
+        p.tail_reach_wgs = (reach + pl.per_wg - 1) / pl.per_wg;
+        PWV_CHECK_ARG(p.tail_reach_wgs <= kMaxReachWgs, "pwv_wavenet_stack_persist_f32: tail dilation %d reaches over %d workgroups (max %d)",
+                      a->tail_dilation, p.tail_reach_wgs, kMaxReachWgs);
+        if (a->affine_x) {
+            PWV_CHECK_ARG(a->affine_out && ((a->G == 2 && a->tail_q == 1) || (a->G == 1 && a->tail_q == 2)),
+                          "pwv_wavenet_stack_persist_f32: the fused affine needs affine_out and (G = 2, tail_q = 1) or (G = 1, tail_q = 2)");
+            p.affine_x = a->affine_x;
+            p.affine_out = a->affine_out;
+            p.pair = pair_words;
+        }
+    } else {
+        PWV_CHECK_ARG(!a->affine_x, "pwv_wavenet_stack_persist_f32: affine_x without a tail");
+    }
+    (void)pair_words;
     p.trace = nullptr;
 #ifdef PWV_PTRACE
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }
 #endif
     hipStream_t s = (hipStream_t)stream;
-    const size_t n16 = align256((size_t)a->G * pl.nwg * kProgStride * 4 + 16) / 16;
+    const size_t n16 = pwv_persist_workspace_bytes(a) / 16;      // (progress words, abort / exit line, pair counters)
     if (!a->workspace_clean)
         hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
     if (a->precision == PWV_PREC_F32)

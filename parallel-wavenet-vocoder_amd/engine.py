@@ -41,7 +41,7 @@ DEFAULT_PRECISION = os.environ.get('PWV_PRECISION', 'f16x3')
 # launch stream and appends (tag, start_event, end_event): bench.py's live kernel timing.
 EVENT_LOG = None
 
-# Environment knobs (five, all read once at import): PWV_PRECISION (above), PWV_PERSIST, PWV_TWO_STREAMS, PWV_FOLD_FIRST,
+# Environment knobs (six, all read once at import): PWV_PRECISION (above), PWV_PERSIST, PWV_TWO_STREAMS, PWV_FOLD_FIRST, PWV_FUSE_TAIL,
 # PWV_ASYNC.  Everything else below is a module attribute that tests / tools set directly.
 #
 # The scalar and shifter nets of a flow are independent dependency chains.  On the per-layer path (PWV_PERSIST=0, or a shape
@@ -52,6 +52,9 @@ TWO_STREAMS = os.environ.get('PWV_TWO_STREAMS', '1') != '0'
 # off to check the fused forms bit for bit against the separate launches)
 FUSE_FIRST = True
 FUSE_HEAD = True
+# the net's last layer + head -- and the flow's affine -- run INSIDE the persistent launch (pwv_persist_args.tail_*, split-fp16 path):
+# a flow is one launch instead of three.  Tests switch it off to check the fused form bit for bit against the separate launches.
+FUSE_TAIL = os.environ.get('PWV_FUSE_TAIL', '1') != '0'      # (PWV_FUSE_TAIL=0: A/B runs of tools/r05_run2.sh)
 HOIST_P = True               # one projection GEMM per forward (project_all); False: every net projects for itself (cross-check in tests)
 # PWV_FOLD_FIRST=0: layer 0 runs its filter|gate GEMM on the rebuilt causal-layer rows (eight MFMA k-steps) instead of on the
 # four scalars they are a function of (one k-step); default: folded.  The only knob that changes bits.
@@ -70,65 +73,144 @@ PERSIST_MAX_LAYERS = 32       # longest run of layers in one persistent launch (
 # the path that is (per-layer launches / exact fp32).  bench.py and graph.py opt out per call (verify=False) and verify for
 # themselves; generate() passes verify=True, which outranks this knob: nothing unverified is ever written to disk.
 ASYNC = os.environ.get('PWV_ASYNC', '0') == '1'
-_persist_status_addr = None
 _persist_ws = {}          # (device, stream) -> zeroed workspace of the persistent launches on that stream
+_persist_ws_retired = []  # workspaces a launch that gave up may still be writing to (kept alive, never handed out again)
 _side_streams = {}
 
+# ---- the library's two sticky words (pinned host memory, read without a device -> host copy) -----------------------------------
+# words[0]: a persistent stack launch gave up (pwv_persist_args.status);  words[1]: an operand left the range of the split-fp16
+# arithmetic (the `range_flag` argument of every entry point that checks).  Every THREAD has its own pair per device
+# (pwv_status_words_alloc): everything a thread enqueues -- on any stream, eagerly or while capturing a graph -- reports into its
+# own words, and its verification reads only those, so two threads serving two streams cannot consume or clear each other's
+# flags.  (A captured graph keeps reporting into the words of the thread that captured it: graph.GraphedVocoder remembers them.)
+_tls = threading.local()      # .words: {device index: StatusWords};  .depth: nesting of reference-shaped calls (verified_call)
+_verify = _tls
 
-def persist_status() -> int:
-    """The library's sticky status word of the persistent stack kernel (pinned host memory): 0 = every launch that has
-    completed so far ran to its end; otherwise a launch gave up and its outputs are invalid."""
-    global _persist_status_addr
-    if _persist_status_addr is None:
+
+class StatusWords(object):
+    __slots__ = ('addr',)
+
+    def __init__(self):
         p = c_void_p()
-        check(_lib.lib().pwv_persist_status(ctypes.byref(p)), 'pwv_persist_status')
-        _persist_status_addr = p.value
-    return ctypes.c_int.from_address(_persist_status_addr).value
+        check(_lib.lib().pwv_status_words_alloc(ctypes.byref(p)), 'pwv_status_words_alloc')
+        self.addr = p.value
+
+    def _w(self, k):
+        return ctypes.c_int.from_address(self.addr + 4 * k)
+
+    persist = property(lambda self: self._w(0).value, lambda self, v: setattr(self._w(0), 'value', int(v)))
+    range = property(lambda self: self._w(1).value, lambda self, v: setattr(self._w(1), 'value', int(v)))
 
 
-def raise_if_persist_failed() -> None:
-    """A give-up of the persistent kernel (unexpected workgroup placement, a poll that ran into its bound) switches the
-    process to the per-layer path and raises: the caller reruns the forward."""
-    global PERSIST
-    code = persist_status()
+def current_words(device=None) -> StatusWords:
+    """This thread's pair of sticky words for `device` (default: the current device); allocated on first use, kept for the life of
+    the process (a launch that was handed them may outlive any scope here)."""
+    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) and device.index is not None
+                                                               else (device if isinstance(device, int) else torch.cuda.current_device()))
+    d = getattr(_tls, 'words', None)
+    if d is None:
+        d = _tls.words = {}
+    w = d.get(idx)
+    if w is None:
+        w = d[idx] = StatusWords()
+    return w
+
+
+def persist_status_ptr() -> int:
+    return current_words().addr
+
+
+def persist_status(words: Optional[StatusWords] = None) -> int:
+    """The sticky give-up word of this thread's persistent stack launches: 0 = every launch that has completed so far ran to its
+    end; otherwise a launch gave up and its outputs are invalid."""
+    return (words or current_words()).persist
+
+
+def poke_persist_status(code: int, words: Optional[StatusWords] = None) -> None:
+    """(tests / tools) Write the give-up word as a launch that gave up would: a real give-up needs a second process on the GPU."""
+    (words or current_words()).persist = code
+
+
+def clear_persist_status(words: Optional[StatusWords] = None) -> None:
+    (words or current_words()).persist = 0
+
+
+# A give-up means the launch's workgroups were not all resident -- another process held CUs.  That is a condition, not a property of
+# this process: the engine SUSPENDS the persistent launches for a number of forwards (per-layer launches: same arithmetic, same
+# bits, ~5 % slower), then tries them again; consecutive give-ups double the pause (16, 32, ... 1024 forwards), a forward that
+# completes on persistent launches resets it.
+PERSIST_RETRY_AFTER = 16
+_persist_cooldown = 0
+_persist_backoff = PERSIST_RETRY_AFTER
+
+
+def persist_suspended() -> bool:
+    return _persist_cooldown > 0
+
+
+def suspend_persist() -> None:
+    global _persist_cooldown, _persist_backoff
+    _persist_cooldown = _persist_backoff
+    _persist_backoff = min(2 * _persist_backoff, 1024)
+    # the launch that gave up may still have workgroups to start (they see the abort word and leave), and it did not clean up
+    # after itself: its workspace is retired, the next persistent launch gets fresh zeros
+    _persist_ws_retired.extend(_persist_ws.values())
+    del _persist_ws_retired[:-8]
+    _persist_ws.clear()
+
+
+def resume_persist() -> None:
+    """(tests / tools) End a suspension now."""
+    global _persist_cooldown, _persist_backoff
+    _persist_cooldown, _persist_backoff = 0, PERSIST_RETRY_AFTER
+
+
+def note_forward() -> None:
+    """One forward has been enqueued (an outermost reference-shaped call, a graph replay): the suspension counts down."""
+    global _persist_cooldown
+    if _persist_cooldown > 0:
+        _persist_cooldown -= 1
+
+
+def raise_if_persist_failed(words: Optional[StatusWords] = None) -> None:
+    """A give-up of the persistent kernel (its workgroups were not all resident, a poll ran into its bound) suspends the
+    persistent launches (suspend_persist) and raises: the caller reruns the forward, which then takes per-layer launches.  The
+    range word is cleared with it: whatever consumed the invalid rows may have raised it, and the rerun must not meet it."""
+    w = words or current_words()
+    code = w.persist
     if code != 0:
-        ctypes.c_int.from_address(_persist_status_addr).value = 0
-        PERSIST = False
-        raise _lib.PwvPersistError('the persistent stack kernel gave up (code %d); its outputs are invalid -- the per-layer path '
-                                   'is used from now on, rerun the forward' % code)
+        w.persist = 0
+        w.range = 0
+        suspend_persist()
+        raise _lib.PwvPersistError('the persistent stack kernel gave up (code %d); its outputs are invalid -- per-layer launches are used '
+                                   'for the next %d forwards, then the persistent launch is tried again; rerun the forward' % (code, _persist_cooldown))
 
 
-_verify = threading.local()      # .depth > 0 inside a reference-shaped call that owns the verification of everything it enqueues (per thread)
-
-
-def clear_persist_status() -> None:
-    if _persist_status_addr is not None:
-        ctypes.c_int.from_address(_persist_status_addr).value = 0
-
-
-def verify_enqueued(where: str = '') -> None:
+def verify_enqueued(where: str = '', words: Optional[StatusWords] = None) -> None:
     """Wait for everything enqueued on this device and raise PwvPersistError / PwvRangeError if a launch that has completed
-    left one of the library's sticky words raised (what a caller of the enqueue-only forms owes before it reads a result)."""
+    left one of this thread's sticky words raised (what a caller of the enqueue-only forms owes before it reads a result)."""
     torch.cuda.synchronize()
-    raise_if_persist_failed()
-    raise_if_range_flag(where)
+    raise_if_persist_failed(words)
+    raise_if_range_flag(where, words)
 
 
 def verified_call(run, verify: Optional[bool] = None):
     """The contract of the reference-shaped entry points (IAFVocoder / WaveNet / LinearIAFLayer / SharedIAFLayer __call__):
     `run(precision_override)` enqueues the forward and returns its result tensor.  By default the OUTERMOST such call then waits
-    for its launches and looks at the two sticky words of the library (pinned host memory: no device -> host copy):
-      * a persistent stack launch gave up (its workgroups were not all resident): the engine has switched to per-layer launches
-        -- same arithmetic, same bits -- and the forward is rerun;
+    for its launches and looks at this thread's two sticky words (pinned host memory: no device -> host copy):
+      * a persistent stack launch gave up (its workgroups were not all resident): the engine suspends the persistent launches
+        (suspend_persist: per-layer launches -- same arithmetic, same bits -- for a while, then another try) and the forward is rerun;
       * an operand left the range of the split-fp16 arithmetic (the reference computes in fp32, models.py:81-82): the forward
         is rerun with precision 'f32'.
     So `pred = model(wav, mel, is_training=False); pred.cpu()` (generate.py:38,68) yields a correct result or an exception,
     never inf from a silent fp16 overflow.  verify=False (or PWV_ASYNC=1, or a call under stream capture, or a call nested in
     another reference-shaped call) only enqueues; the caller then owns verify_enqueued() / IAFVocoder.verify()."""
-    global PERSIST
+    global _persist_backoff
     if verify is None:
         verify = not ASYNC
     depth = getattr(_verify, 'depth', 0)
+    if depth == 0:
+        note_forward()
     if depth > 0 or not verify or torch.cuda.is_current_stream_capturing():
         _verify.depth = depth + 1
         try:
@@ -142,13 +224,16 @@ def verified_call(run, verify: Optional[bool] = None):
         if persist_status() != 0:
             clear_persist_status()
             clear_range_flag()          # (whatever consumed the invalid rows may have raised it)
-            PERSIST = False
+            suspend_persist()
             import warnings
             warnings.warn('pwv: a persistent stack launch gave up (its workgroups were not all resident -- another process on this GPU?); '
-                          'the forward is rerun on per-layer launches (same arithmetic, same bits) and the process stays on them')
+                          'the forward is rerun on per-layer launches (same arithmetic, same bits), which the next %d forwards use too '
+                          'before the persistent launch is tried again' % _persist_cooldown)
             out = run(None)
             torch.cuda.current_stream().synchronize()
             raise_if_persist_failed()
+        elif _persist_cooldown == 0:
+            _persist_backoff = PERSIST_RETRY_AFTER      # (a forward on persistent launches -- or one that never needed them -- went through)
         if range_flag_raised():
             clear_range_flag()
             import warnings
@@ -180,7 +265,7 @@ def _persist_runs(L: int, first: int = 1) -> List[Tuple[int, int]]:
 
 def _use_persist(G: int, n: int, t: int, dilations, first: int = 1) -> bool:
     L = len(dilations)
-    if PERSIST is False or L < 4:
+    if PERSIST is False or _persist_cooldown > 0 or L < 4:
         return False
     if PERSIST == 'auto' and n * t > PERSIST_AUTO_MAX_ROWS:
         return False
@@ -204,33 +289,26 @@ def _net_streams(device):
 
 # ---- range guard of the split-fp16 arithmetic (include/pwv_hip.h, "Range guard") -------------------------------
 F16_LIMIT = 65000.0          # fp16 max is 65504; stay below the value that rounds up to inf
-_range_flag_addr = None
 _range_warned = set()
 
 
 def range_flag_ptr() -> int:
-    """Address of the library's sticky overflow flag (pinned host memory, also valid on the device)."""
-    global _range_flag_addr
-    if _range_flag_addr is None:
-        p = c_void_p()
-        check(_lib.lib().pwv_range_flag(ctypes.byref(p)), 'pwv_range_flag')
-        _range_flag_addr = p.value
-    return _range_flag_addr
+    """Address of this thread's sticky overflow flag (pinned host memory, also valid on the device)."""
+    return current_words().addr + 4
 
 
-def range_flag_raised() -> bool:
-    """True once a split-fp16 forward that has COMPLETED met an out-of-range operand (no synchronisation here)."""
-    return _range_flag_addr is not None and ctypes.c_int.from_address(_range_flag_addr).value != 0
+def range_flag_raised(words: Optional[StatusWords] = None) -> bool:
+    """True once a split-fp16 forward of this thread that has COMPLETED met an out-of-range operand (no synchronisation here)."""
+    return (words or current_words()).range != 0
 
 
-def clear_range_flag() -> None:
-    if _range_flag_addr is not None:
-        ctypes.c_int.from_address(_range_flag_addr).value = 0
+def clear_range_flag(words: Optional[StatusWords] = None) -> None:
+    (words or current_words()).range = 0
 
 
-def raise_if_range_flag(where: str = '') -> None:
-    if range_flag_raised():
-        clear_range_flag()
+def raise_if_range_flag(where: str = '', words: Optional[StatusWords] = None) -> None:
+    if range_flag_raised(words):
+        clear_range_flag(words)
         raise _lib.PwvRangeError("a split-fp16 ('f16x3') forward%s met an activation or input beyond fp16's exponent range "
                                  "(or a non-finite one): its result is not trustworthy -- rerun with precision='f32'"
                                  % (' (%s)' % where if where else ''))
@@ -530,10 +608,12 @@ def _same_structure(a, b) -> bool:
             and a.condition_channels == b.condition_channels and a.filter_width == b.filter_width)
 
 
-def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec):
-    """Layer 0 (one launch), layers 1 .. L-2 (ONE persistent launch), layer L-1 with the head behind it (one launch); all
-    nets of the flow in every launch, all on the current stream.  `bufs[g]` holds THREE tile32 buffers: the persistent
-    launch rotates through them (include/pwv_hip.h, pwv_persist_args.x_ring)."""
+def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec, affine=None):
+    """Layers 0 .. L-2 as ONE persistent launch (layer 0 a launch of its own when it cannot rebuild the causal layer itself), with
+    layer L-1 + the head behind it -- and, given `affine` = (x, out), the flow's affine out = x*s + b -- INSIDE that launch on the
+    split-fp16 path (FUSE_TAIL; otherwise one more launch for them); all nets of the flow in every launch, all on the current
+    stream.  `bufs[g]` holds THREE tile32 buffers: the persistent launch rotates through them (include/pwv_hip.h,
+    pwv_persist_args.x_ring).  Returns True when the affine was evaluated by the launch."""
     G, L = len(nets), plans[0].n_layers
     net0 = nets[0]
     hop, offset, frames = cond_geom
@@ -560,7 +640,11 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
 
     # the residual layers (0 or) 1 .. L-2 as persistent launches of at most PERSIST_MAX_LAYERS layers each, handing the ring on
     rot, out_slot = 0, 2
-    for j0, cnt in _persist_runs(L, 1 if x_first is None else 0):
+    runs = _persist_runs(L, 1 if x_first is None else 0)
+    Q = net0.out_channels
+    tail = FUSE_TAIL and FUSE_HEAD and prec == _lib.PREC_F16X3
+    affine_fused = bool(tail and affine is not None and ((G == 2 and Q == 1) or (G == 1 and Q == 2)))
+    for j0, cnt in runs:
         pa = _lib.PersistArgs()
         pa.G, pa.n_layers = G, cnt
         dil = (ctypes.c_int * cnt)(*[int(d) for d in net0.dilations[j0:j0 + cnt]])
@@ -593,6 +677,16 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         if ws is None or ws.numel() < nbytes:
             ws = _persist_ws[wkey] = torch.zeros((max(nbytes, 1 << 16),), dtype=torch.uint8, device=bufs[0][0].device)
         pa.workspace, pa.workspace_bytes, pa.workspace_clean = ws.data_ptr(), nbytes, 1
+        pa.status = persist_status_ptr()
+        last_run = (j0, cnt) == runs[-1]
+        if tail and last_run:             # layer L-1 + head (+ affine) behind this run's layers, inside the launch
+            for g in range(G):
+                pa.tail_layer[g] = plans[g].packed_layers.data_ptr() + 4 * stride * (L - 1)
+                pa.tail_head[g] = plans[g].packed_head.data_ptr()
+                pa.tail_out[g] = outs[g].data_ptr()
+            pa.tail_q, pa.tail_dilation = Q, int(net0.dilations[L - 1])
+            if affine_fused:
+                pa.affine_x, pa.affine_out = affine[0].data_ptr(), affine[1].data_ptr()
         ev = None
         if EVENT_LOG is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -600,9 +694,11 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
         if ev is not None:
             ev[1].record()
-            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt, 1 if j0 == 0 else 0))
+            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt, 1 if j0 == 0 else 0, 1 if (tail and last_run) else 0))
         out_slot = (cnt - 1 + rot) % 3      # where this run left its last layer
         rot = (out_slot + 1) % 3            # the next run's input buffer is (2 + rot') % 3 == out_slot
+    if tail:
+        return affine_fused
     spare = (out_slot + 1) % 3
 
     la = layer_args(L - 1, out_slot, spare)
@@ -622,6 +718,7 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         ha.N, ha.T, ha.Q = n, t, net0.out_channels
         ha.in_mode, ha.precision = _lib.HEAD_IN_GATED, prec
         check(lib.pwv_wavenet_head_f32(ctypes.byref(ha), s), 'pwv_wavenet_head_f32')
+    return False
 
 
 _bank_cache = {}      # tuple of plan ids -> (plans (kept alive), concatenated proj_w [K, total], proj_b [total], column offsets)
@@ -677,6 +774,26 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
              max_workgroups: int = 0) -> List[torch.Tensor]:
     """Evaluate 1 or 2 structurally identical fused-capable WaveNets on the same input/condition.
     Returns one [N, T, Q] tensor per net."""
+    return _run_nets(nets, x, cond, precision, max_workgroups, None)[0]
+
+
+def run_flow(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None) -> torch.Tensor:
+    """One IAF flow (modules.py:53-60): out = x * scale + shift with (scale, shift) = the outputs of two scalar-input nets, or
+    the two outputs of one shared net.  On the default path the whole flow is ONE persistent launch (the affine is evaluated
+    inside it, pwv_persist_args.affine_x); otherwise the nets' launches are followed by the affine kernel."""
+    x = _require_cuda_f32(x, 'input')
+    out = torch.empty_like(x)
+    outs, done = _run_nets(nets, x, cond, precision, 0, out)
+    if done:
+        return out
+    if len(outs) == 2:
+        return iaf_affine_op(x, outs[0], outs[1], 1)
+    flat = outs[0].reshape(-1)
+    return iaf_affine_op(x, flat, flat[1:], 2)
+
+
+def _run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str], max_workgroups: int, affine_out: Optional[torch.Tensor]):
+    """run_nets / run_flow: ([one [N, T, Q] tensor per net], whether `affine_out` = x*s + b was written by the launches)."""
     lib = _lib.lib()
     prec = PRECISIONS[precision or DEFAULT_PRECISION]
     x = _require_cuda_f32(x, 'input_batch')
@@ -691,7 +808,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     if qin != net0.in_channels:
         raise ValueError('input has %d channels, net expects %d' % (qin, net0.in_channels))
     if n * t == 0:
-        return [torch.empty((n, t, net0.out_channels), dtype=torch.float32, device=x.device) for _ in nets]
+        return [torch.empty((n, t, net0.out_channels), dtype=torch.float32, device=x.device) for _ in nets], False
     dev = x.device
     s = _stream()
 
@@ -724,7 +841,7 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
             _range_warned.add(key)
             import warnings
             warnings.warn("pwv: weights of %s exceed the range of the split-fp16 arithmetic; using precision 'f32' for it" % (key,))
-        return run_nets(nets, x, cond, precision='f32', max_workgroups=max_workgroups)
+        return _run_nets(nets, x, cond, 'f32', max_workgroups, affine_out)
     x_limit = min(p.x_limit for p in plans)
     L = plans[0].n_layers
     for net, plan in zip(nets, plans):
@@ -825,9 +942,10 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     outs = [torch.empty((n, t, Q), dtype=torch.float32, device=dev) for _ in nets]
 
     if persist:
-        _run_stack_persist(lib, nets, plans, projs, bufs, outs, x if first_fused else None, x_limit, row_stride,
-                           (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec)
-        return outs
+        aff = (x, affine_out) if (affine_out is not None and qin == 1) else None
+        done = _run_stack_persist(lib, nets, plans, projs, bufs, outs, x if first_fused else None, x_limit, row_stride,
+                                  (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec, aff)
+        return outs, done
     if two:
         for g in range(2):
             side[g].wait_stream(main)
@@ -878,4 +996,4 @@ def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = N
     if two:
         for g in range(2):
             main.wait_stream(side[g])
-    return outs
+    return outs, False

@@ -54,6 +54,8 @@ class GraphedVocoder(object):
                 self.model(None, self.mel, is_training=False, z=self.z)
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        # the captured launches carry THIS thread's sticky words (engine.current_words): verify() reads these, whoever replays
+        self._words = engine.current_words(self.device)
         # thread_local: only this thread's calls are policed during capture (an RCCL watchdog thread of a multi-rank
         # job may touch the runtime meanwhile); everything captured here is enqueued from this thread
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
@@ -64,14 +66,16 @@ class GraphedVocoder(object):
     @staticmethod
     def _launch_mode():
         """what decides WHICH launches a forward enqueues, besides the weights: a graph captured under another value is stale"""
-        return (engine.PERSIST, engine.TWO_STREAMS, engine.FOLD_FIRST, engine.FUSE_FIRST, engine.FUSE_HEAD, engine.HOIST_P,
-                engine.PERSIST_MAX_LAYERS, engine.PERSIST_MIN_UNITS, engine.DEFAULT_PRECISION)
+        return (engine.PERSIST, engine.persist_suspended(), engine.TWO_STREAMS, engine.FOLD_FIRST, engine.FUSE_FIRST, engine.FUSE_HEAD,
+                engine.FUSE_TAIL, engine.HOIST_P, engine.PERSIST_MAX_LAYERS, engine.PERSIST_MIN_UNITS, engine.DEFAULT_PRECISION)
 
     def verify(self):
-        """Replays only enqueue: wait for them and raise like IAFVocoder.verify().  After a PwvPersistError the engine is on the
-        per-layer path; the graph is re-captured on it here, so the caller's rerun replays launches that can complete."""
+        """Replays only enqueue: wait for them and raise like IAFVocoder.verify().  After a PwvPersistError the engine has
+        suspended the persistent launches (engine.suspend_persist); the graph is re-captured on the per-layer path here, so the
+        caller's rerun replays launches that can complete -- and once the suspension has counted down (one tick per replay) the
+        next call re-captures on the persistent path again (_launch_mode)."""
         try:
-            engine.verify_enqueued()
+            engine.verify_enqueued(words=self._words)
         except engine._lib.PwvPersistError:
             self._capture()
             raise
@@ -80,6 +84,7 @@ class GraphedVocoder(object):
         """melspec [N, t_mel, n_mels]; z [N, length, 1] or None (sample Logistic(0,1), models.py:32-33).
         Returns the graph's output buffer [N, length, 1]: valid until the next call (clone it to keep it).  Enqueue-only, like
         IAFVocoder.__call__(verify=False): call verify() before reading the result."""
+        engine.note_forward()
         if self.store.version != self._version or self._mode != self._launch_mode():
             self._capture()      # weights changed (the captured launches point at stale packs) or the engine switched launch paths
         if tuple(melspec.shape) != tuple(self.mel.shape):

@@ -327,6 +327,8 @@ class LinearIAFLayer(object):
         both_fused = (isinstance(sc, WaveNet) and isinstance(sh, WaveNet) and sc.fused_supported(condition)
                       and sh.fused_supported(condition) and engine._same_structure(sc, sh)
                       and sc.precision == sh.precision)
+        if both_fused and input.shape[-1] == 1 and sc.out_channels == 1:
+            return engine.run_flow([sc, sh], input, condition, precision=prec or sc.precision)      # (one launch per flow on the default path)
         if both_fused:
             scale, shift = engine.run_nets([sc, sh], input, condition, precision=prec or sc.precision)
         elif prec is not None and isinstance(sc, WaveNet) and isinstance(sh, WaveNet):
@@ -360,6 +362,8 @@ class SharedIAFLayer(object):
 
     def _enqueue(self, input, condition, prec=None):
         net = self.net
+        if net.fused_supported(condition) and input.shape[-1] == 1 and net.out_channels == 2:
+            return engine.run_flow([net], input, condition, precision=prec or net.precision)
         if prec is not None and net.fused_supported(condition):
             y = engine.run_nets([net], input, condition, precision=prec)[0]
         else:

@@ -33,9 +33,11 @@ def _nets(gpu, L, G, seed=3, cond_channels=80):
 @pytest.fixture()
 def persist_knobs():
     from pwv_amd import engine
-    saved = (engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS, engine.FOLD_FIRST)
+    saved = (engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS, engine.FOLD_FIRST, engine.FUSE_TAIL)
+    engine.resume_persist()
     yield engine
-    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS, engine.FOLD_FIRST = saved
+    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS, engine.FOLD_FIRST, engine.FUSE_TAIL = saved
+    engine.resume_persist()
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
@@ -75,6 +77,58 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
         engine.EVENT_LOG = None
     runs = engine._persist_runs(L, 0)       # (scalar-input nets: the launch starts with the net's layer 0)
     assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 1)      # it really was persistent
+
+
+@pytest.mark.parametrize('n,t,L,G,Q,min_units,max_layers', [
+    (1, 160000, 10, 2, 1, 0, 32), (1, 16000, 30, 2, 1, 0, 32), (3, 8000, 10, 2, 1, 0, 32), (1, 16000, 12, 2, 1, 1, 32),
+    (1, 48000, 13, 2, 1, 0, 4),       # runs of 4 + 4 + 3 layers: the tail rides on the LAST run
+    (1, 96, 5, 2, 1, 0, 32), (1, 40, 4, 2, 1, 0, 32),       # three units / two units in all (a ragged last unit)
+    (2, 24000, 10, 1, 2, 0, 32), (1, 2400, 6, 1, 2, 2, 32)])        # one shared net with two outputs (BASELINE config 2): the affine in place
+def test_tail_and_affine_inside_the_launch_are_bit_identical_to_the_separate_launches(gpu, persist_knobs, n, t, L, G, Q, min_units, max_layers):
+    """Round 5: the net's last layer + head (modules.py:145-165) and the flow's affine (modules.py:59) run INSIDE the persistent
+    launch (pwv_persist_args.tail_*: a flow is one launch instead of three).  Same operations in the same order as
+    layer_f16x3_kernel<..., HEAD> and the affine kernel: the nets' outputs and the flow's output agree bit for bit with the
+    separate launches (FUSE_TAIL off) and with the per-layer path -- three times in a row on one workspace (the pair counters
+    and progress words are left clean), eager."""
+    import torch
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    engine = persist_knobs
+    store = VariableStore(device=gpu, seed=5)
+    kw = dict(batch_size=n, dilations=(D10 * 3)[:L], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
+              quantization_channels=Q, use_biases=True, condition_channels=80, use_skip_connection=False, is_training=False, store=store)
+    nets = [WaveNet(name='n%d' % g, **kw) for g in range(G)]
+    g = torch.Generator().manual_seed(n * 13 + L)
+    x = torch.randn((n, t, 1), generator=g).to(gpu)
+    cond = engine.RepeatedCondition(torch.rand((n, t // 80 + 1, 80), generator=g).to(gpu), 80, 40, t)
+    engine.run_nets(nets, x, cond)  # creates the variables
+    for name in list(store.vars):
+        if store.vars[name].dim() == 1:
+            store.vars[name].normal_(0, 0.1)
+    store.version += 1
+    engine.PERSIST = False
+    ref_outs = [o.clone() for o in engine.run_nets(nets, x, cond)]
+    ref_flow = engine.run_flow(nets, x, cond).clone()
+    engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS = True, min_units, max_layers
+    engine.FUSE_TAIL = False
+    sep_flow = engine.run_flow(nets, x, cond).clone()
+    torch.cuda.synchronize()
+    assert engine.persist_status() == 0 and torch.equal(sep_flow, ref_flow)
+    engine.FUSE_TAIL = True
+    log = engine.EVENT_LOG = []
+    try:
+        for _ in range(3):
+            outs = engine.run_nets(nets, x, cond)
+            flow = engine.run_flow(nets, x, cond)
+            torch.cuda.synchronize()
+            assert engine.persist_status() == 0
+            for a, b in zip(ref_outs, outs):
+                assert torch.equal(a, b)
+            assert torch.equal(flow, ref_flow)
+    finally:
+        engine.EVENT_LOG = None
+    runs = engine._persist_runs(L, 0)
+    assert len(log) == 6 * len(runs) and sum(e[6] for e in log) == 6      # every forward's last run carried the tail
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
@@ -154,16 +208,23 @@ def test_whole_model_persistent_eager_and_graph_replay(gpu, persist_knobs):
 
 def test_persistent_give_up_is_loud_and_falls_back(gpu, persist_knobs):
     """The kernel reports a give-up (unexpected placement, a poll that ran into its bound) through a sticky word in pinned
-    host memory; the host then raises and uses the per-layer path from then on.  (The word is poked from the host here:
-    a real give-up needs a broken chip.)"""
+    host memory; the host then raises and SUSPENDS the persistent launches: per-layer launches for the next
+    PERSIST_RETRY_AFTER forwards, then another try (a give-up is a condition of the GPU -- a co-tenant -- not of this process).
+    The range word goes with it (garbage downstream may have raised it; the rerun must not meet it).  (The word is poked from the
+    host here: a real give-up needs a second process on the GPU, tools/co_tenant_check.sh.)"""
     from pwv_amd._lib import PwvPersistError
     engine = persist_knobs
     engine.PERSIST = True
-    assert engine.persist_status() == 0
-    ctypes.c_int.from_address(engine._persist_status_addr).value = 4
+    assert engine.persist_status() == 0 and not engine.persist_suspended()
+    engine.poke_persist_status(4)
+    engine.current_words().range = 1
     with pytest.raises(PwvPersistError, match='gave up'):
         engine.raise_if_persist_failed()
-    assert engine.PERSIST is False and engine.persist_status() == 0
+    assert engine.PERSIST is True and engine.persist_suspended() and engine.persist_status() == 0 and not engine.range_flag_raised()
+    assert not engine._use_persist(2, 1, 16000, [1, 2, 4, 8, 16, 32], 0)
+    for _ in range(engine.PERSIST_RETRY_AFTER):
+        engine.note_forward()
+    assert not engine.persist_suspended() and engine._use_persist(2, 1, 16000, [1, 2, 4, 8, 16, 32], 0)
 
 
 def test_auto_policy_takes_the_persistent_launch_where_the_library_supports_the_shape(gpu, persist_knobs):

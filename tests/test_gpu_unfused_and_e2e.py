@@ -334,20 +334,30 @@ def test_graphed_vocoder_recaptures_when_the_engine_switches_launch_paths(gpu):
         captured = graphed.graph
         assert torch.equal(graphed(mel, z=z), want)
         graphed.verify()
-        engine.persist_status()
-        ctypes.c_int.from_address(engine._persist_status_addr).value = 4
+        # BOTH words raised, as after a real give-up whose garbage tripped the range guard downstream: verify() raises the
+        # persist error, clears the range word with it, re-captures -- and the prescribed rerun goes through
+        engine.poke_persist_status(4)
+        engine.current_words().range = 1
         with pytest.raises(PwvPersistError):
             graphed.verify()
-        assert engine.PERSIST is False and graphed.graph is not captured      # re-captured on the per-layer path
+        assert engine.persist_suspended() and graphed.graph is not captured      # re-captured on the per-layer path
+        assert not engine.range_flag_raised()
         assert torch.equal(graphed(mel, z=z), want)
         graphed.verify()
+        # ... the suspension counts down with the replays; when it is over the next call re-captures on the persistent path
+        recaptured = graphed.graph
+        for _ in range(engine.PERSIST_RETRY_AFTER):
+            assert torch.equal(graphed(mel, z=z), want)
+        graphed.verify()
+        assert not engine.persist_suspended() and graphed.graph is not recaptured
         # ... and a switch it was not told about: noticed at the next replay
         recaptured = graphed.graph
-        engine.PERSIST = True
+        engine.PERSIST = False
         assert torch.equal(graphed(mel, z=z), want) and graphed.graph is not recaptured
         graphed.verify()
     finally:
         engine.PERSIST = saved
+        engine.resume_persist()
 
 
 def test_bench_multi_rank_control_flow_on_one_gpu():

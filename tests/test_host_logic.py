@@ -221,8 +221,9 @@ def test_roofline_reproduces_from_the_committed_profiles(case, precision, name):
     # the bench line's own per-forward / per-launch figures -> algorithmic bytes of the same launches
     if 'alg_bytes_per_forward' in roof_b:
         layer_bytes = roof_b['alg_bytes_per_net_layer'] // rows
+        tail = roof_b.get('tail_net_layers_per_forward', 0) * roof_b.get('alg_bytes_per_tail_net_layer', 0)      # (round 5: last layer + head inside the launch)
         assert roof_b['alg_bytes_per_forward'] == rows * (roof_b['net_layers_per_forward'] * layer_bytes
-                                                            - roof_b['first_net_layers_per_forward'] * (layer_bytes // 2 - 4))
+                                                            - roof_b['first_net_layers_per_forward'] * (layer_bytes // 2 - 4)) + tail
         assert tj['algorithmic_bytes_total'] == tj['forwards'] * roof_b['alg_bytes_per_forward']
         assert tj['launches'] == tj['forwards'] * roof_b['launches_per_forward']
     else:

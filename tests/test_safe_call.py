@@ -29,14 +29,17 @@ def stub_engine(monkeypatch):
     state = {'persist': 0, 'range': False}
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: _Stream(log))
     monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
-    monkeypatch.setattr(engine, 'persist_status', lambda: state['persist'])
-    monkeypatch.setattr(engine, 'clear_persist_status', lambda: state.__setitem__('persist', 0))
-    monkeypatch.setattr(engine, 'range_flag_raised', lambda: state['range'])
-    monkeypatch.setattr(engine, 'clear_range_flag', lambda: state.__setitem__('range', False))
+    monkeypatch.setattr(engine, 'persist_status', lambda words=None: state['persist'])
+    monkeypatch.setattr(engine, 'clear_persist_status', lambda words=None: state.__setitem__('persist', 0))
+    monkeypatch.setattr(engine, 'range_flag_raised', lambda words=None: state['range'])
+    monkeypatch.setattr(engine, 'clear_range_flag', lambda words=None: state.__setitem__('range', False))
+    monkeypatch.setattr(engine, 'raise_if_persist_failed', lambda words=None: None)
     monkeypatch.setattr(engine, 'ASYNC', False)
     saved = engine.PERSIST
+    engine.resume_persist()
     yield engine, log, state
     engine.PERSIST = saved
+    engine.resume_persist()
 
 
 def test_clean_call_synchronises_once_and_returns(stub_engine):
@@ -52,13 +55,48 @@ def test_give_up_inside_the_call_is_rerun_on_per_layer_launches(stub_engine):
     runs = []
 
     def run(prec):
-        runs.append((prec, engine.PERSIST))
+        runs.append((prec, engine.persist_suspended()))
         if len(runs) == 1:
             state['persist'], state['range'] = 4, True      # the give-up, and garbage downstream tripping the range guard
         return 'y%d' % len(runs)
     with pytest.warns(UserWarning, match='rerun on per-layer launches'):
         assert engine.verified_call(run) == 'y2'
-    assert runs == [(None, 'auto'), (None, False)] and engine.PERSIST is False and not state['range']
+    assert runs == [(None, False), (None, True)] and engine.PERSIST == 'auto' and not state['range']
+
+
+def test_a_give_up_suspends_the_persistent_launches_and_they_come_back(stub_engine):
+    """one give-up (a transient co-tenant) must not cost 5 % for the life of the process.  The engine stays on
+    per-layer launches for PERSIST_RETRY_AFTER forwards, then tries the persistent launch again; a second give-up in a row
+    doubles the pause, a forward that goes through resets it."""
+    engine, log, state = stub_engine
+    engine.PERSIST = 'auto'
+    seen = []
+
+    def run(prec):
+        seen.append(engine.persist_suspended())
+        return 'y'
+
+    def give_up_once(prec):
+        if not engine.persist_suspended():
+            state['persist'] = 4
+        return run(prec)
+    with pytest.warns(UserWarning, match='per-layer launches'):
+        engine.verified_call(give_up_once)
+    k = engine.PERSIST_RETRY_AFTER
+    for _ in range(k):
+        engine.verified_call(run)
+    # the call with the give-up: [persistent, rerun suspended]; the first k - 1 forwards after it are suspended (the rerun consumed
+    # no tick, the k-th tick ends the pause at the START of the k-th forward)
+    assert seen[:2] == [False, True] and seen[2:2 + k - 1] == [True] * (k - 1) and seen[2 + k - 1] is False
+    assert not engine.persist_suspended() and engine._persist_backoff == k          # ... and a clean forward reset the back-off
+    del seen[:]
+    with pytest.warns(UserWarning):
+        engine.verified_call(give_up_once)
+    for _ in range(k - 1):
+        engine.verified_call(run)
+    with pytest.warns(UserWarning):
+        engine.verified_call(give_up_once)          # gives up again on its first try after the pause
+    assert engine._persist_cooldown == 2 * k        # consecutive give-ups: the pause doubles
 
 
 def test_range_flag_inside_the_call_is_rerun_in_f32(stub_engine):
@@ -174,21 +212,22 @@ def test_give_up_inside_a_call_is_repaired_inside_the_call(gpu, monkeypatch):
         engine.PERSIST = False
         want = model(None, mel_t, is_training=False, z=z_t).clone()
         engine.PERSIST = True
-        engine.persist_status()                 # (materialises the word's address)
         real, poked = engine._run_stack_persist, []
 
         def spy(*a, **k):
-            real(*a, **k)
+            r = real(*a, **k)
             if not poked:
                 poked.append(1)
-                ctypes.c_int.from_address(engine._persist_status_addr).value = 4
+                engine.poke_persist_status(4)
+            return r
         monkeypatch.setattr(engine, '_run_stack_persist', spy)
         with pytest.warns(UserWarning, match='per-layer launches'):
             got = model(None, mel_t, is_training=False, z=z_t)
-        assert poked and engine.PERSIST is False and engine.persist_status() == 0
+        assert poked and engine.persist_suspended() and engine.PERSIST is True and engine.persist_status() == 0
         assert torch.equal(got, want)
     finally:
         engine.PERSIST = saved
+        engine.resume_persist()
 
 
 @pytest.mark.gpu
@@ -233,3 +272,50 @@ def test_a_parity_test_cannot_pass_on_the_calls_own_repair(gpu):
     # and the same model, in range, answers in its own arithmetic without a warning
     y = model(None, torch.from_numpy(mel).to(gpu), is_training=False, z=torch.from_numpy(z).to(gpu)).cpu().numpy()
     assert np.abs(y - O.iaf_vocoder_forward(O.init_weights(cfg, seed=6), mel, z, cfg)).max() <= TOL_F32
+
+
+@pytest.mark.gpu
+@pytest.mark.allow_pwv_repair
+def test_two_threads_on_two_streams_do_not_see_each_others_flags(gpu):
+    """the sticky words are per THREAD (engine.current_words), so a thread whose forwards trip the
+    range guard (and are repaired in exact fp32, with a warning) cannot make another thread's in-range split-fp16 forward rerun --
+    or, worse, consume that thread's flag.  Thread B's results are the split-fp16 bits of a single-threaded run, every time."""
+    import threading
+    import warnings
+    from pwv_amd import engine
+    from pwv_amd.models import IAFVocoder
+    cfg = small_cfg()
+    n, length = 1, 960
+    mel, z = O.synthetic_inputs(n, length, cfg)
+    mel_t, z_t = torch.from_numpy(mel).to(gpu), torch.from_numpy(z).to(gpu)
+    bad_t = torch.from_numpy((mel * 1e5).astype(np.float32)).to(gpu)
+    model_a, store_a = _model(gpu, cfg, length, n)
+    model_b, _ = _model(gpu, cfg, length, n)
+    want_b = model_b(None, mel_t, is_training=False, z=z_t).clone()                      # split-fp16, single-threaded
+    m32 = IAFVocoder(batch_size=n, length=length, store=store_a, precision='f32')
+    want_a = m32(None, bad_t, is_training=False, z=z_t).clone()                          # what A's repaired calls must return
+    main_words = engine.current_words().addr
+    res = {'a': [], 'b': [], 'words': [], 'err': []}
+
+    def worker(name, model, inp, rounds):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=gpu)):
+                res['words'].append(engine.current_words().addr)
+                for _ in range(rounds):
+                    res[name].append(model(None, inp, is_training=False, z=z_t).clone())
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:          # noqa: BLE001
+            res['err'].append((name, e))
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        ta = threading.Thread(target=worker, args=('a', model_a, bad_t, 6))
+        tb = threading.Thread(target=worker, args=('b', model_b, mel_t, 24))
+        ta.start(); tb.start(); ta.join(); tb.join()
+    assert not res['err'], res['err']
+    assert len(set(res['words'] + [main_words])) == 3                                    # three threads, three pairs of words
+    assert len(res['a']) == 6 and all(torch.equal(y, want_a) for y in res['a'])          # A: repaired in exact fp32, every time
+    assert len(res['b']) == 24 and all(torch.equal(y, want_b) for y in res['b'])         # B: its own arithmetic, never rerun
+    msgs = [str(w.message) for w in caught if str(w.message).startswith('pwv:')]
+    assert len(msgs) == 6 and all('exact fp32' in m for m in msgs)                       # exactly A's six repairs, nothing for B
+    assert not engine.range_flag_raised() and engine.persist_status() == 0               # (this thread's words: untouched)
