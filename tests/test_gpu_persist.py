@@ -97,6 +97,8 @@ def test_tail_and_affine_inside_the_launch_are_bit_identical_to_the_separate_lau
     store = VariableStore(device=gpu, seed=5)
     kw = dict(batch_size=n, dilations=(D10 * 3)[:L], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
               quantization_channels=Q, use_biases=True, condition_channels=80, use_skip_connection=False, is_training=False, store=store)
+    if Q == 2:
+        kw['input_channels'] = 1          # (the shared net of BASELINE config 2: one input, scale and shift out; models.py here builds it so)
     nets = [WaveNet(name='n%d' % g, **kw) for g in range(G)]
     g = torch.Generator().manual_seed(n * 13 + L)
     x = torch.randn((n, t, 1), generator=g).to(gpu)
