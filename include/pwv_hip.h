@@ -78,6 +78,14 @@ int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y,
  * relative per product: the arithmetic of PWV_PREC_F16X3); 5x fewer matrix-pipe cycles */
 int pwv_linear_split_f32(const float* x, const float* w, const float* bias, float* y,
                          int M, int K, int Nout, int relu, pwv_stream_t stream);
+/* The prologue of a 'repeat'-conditioned forward as ONE launch (PWV_PREC_F16X3 / PWV_PREC_F16 arithmetic of pwv_linear_split_f32):
+ *   frames[M, C] = relu(mel[M, n_mels] @ dense[n_mels, C])                      models.py:128-130 (no bias)
+ *   P[M, Nout]   = frames @ bank_w[C, Nout] + bank_b[Nout]                      the hoisted projections of modules.py:216-228
+ *   *range_flag  = 1 if any mel value is non-finite or beyond `limit`           (range guard; range_flag may be NULL)
+ * bit-identical to pwv_range_check_f32 + pwv_linear_split_f32 (relu) + pwv_linear_split_f32; n_mels, C multiples of 8, <= 80;
+ * `frames` may be NULL when only P is wanted. */
+int pwv_cond_project_f32(const float* mel, const float* dense, int n_mels, const float* bank_w, const float* bank_b, float* frames,
+                         float* P, int M, int C, int Nout, float limit, int* range_flag, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * IAFVocoder._upsample_cond, 'repeat' branch: tile + reshape + crop   models.py:131-133

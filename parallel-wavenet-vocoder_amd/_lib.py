@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
-    'pwv_linear_split_f32', 'pwv_pack_first_fold_f16x3', 'pwv_pack_first_fold_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_status_words_alloc', 'pwv_status_words_free', 'pwv_range_check_f32', 'pwv_range_stats_f32',
+    'pwv_linear_split_f32', 'pwv_cond_project_f32', 'pwv_pack_first_fold_f16x3', 'pwv_pack_first_fold_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_status_words_alloc', 'pwv_status_words_free', 'pwv_range_check_f32', 'pwv_range_stats_f32',
     'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32',
     'pwv_wav_to_mel_db_f32', 'pwv_pack_proj_f32', 'pwv_instance_norm_workspace_bytes', 'pwv_instance_norm_f32', 'pwv_channel_affine_f32', 'pwv_add_f32', 'pwv_gate_f32',
 )
@@ -233,6 +233,7 @@ def _declare(lib):
     lib.pwv_wavenet_stack_persist_f32.argtypes = [POINTER(PersistArgs), c_void_p]
     lib.pwv_range_stats_f32.argtypes = [f32p] * 8 + [c_int, f32p, c_void_p]
     lib.pwv_range_flag.argtypes = [POINTER(c_void_p)]
+    lib.pwv_cond_project_f32.argtypes = [f32p, f32p, c_int, f32p, f32p, f32p, f32p, c_int, c_int, c_int, ctypes.c_float, c_void_p, c_void_p]
     lib.pwv_status_words_alloc.argtypes = [POINTER(c_void_p)]
     lib.pwv_status_words_free.argtypes = [c_void_p]
     lib.pwv_range_check_f32.argtypes = [f32p, c_int64, ctypes.c_float, c_void_p, c_void_p]

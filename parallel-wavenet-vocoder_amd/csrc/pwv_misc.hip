@@ -274,6 +274,161 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
     }
 }
 
+// The forward's prologue in ONE launch (round 5): the frame-rate condition c = relu(mel @ dense) (models.py:128-130, no bias), the
+// frame-rate projections P = c @ [gc_filter | gc_gate of every layer of every net] + biases (hoisted modules.py:216-228,
+// engine.project_all) and the range check of the mel (include/pwv_hip.h "Range guard") used to be three launches; at short inputs
+// they were a third of a one-flow forward.  Every workgroup of the projection GEMM recomputes c for ITS row tiles with exactly the
+// MFMA sequence of linear_split_kernel<5> (3 column tiles x 5 k-steps x 3 products: +45 MFMAs next to the tile's 60), passes it
+// through a per-wave LDS tile into the operand layout (lane = row), and goes on as linear_split_kernel<5> does -- so c and P are
+// bit-identical to the separate launches (tests/test_gpu_parity.py).  K0 = n_mels <= 80, K = condition channels <= 80.
+constexpr int kCtStride = 84;
+__global__ __launch_bounds__(256) void cond_proj_kernel(const float* __restrict__ x0, const float* __restrict__ w0, int K0,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                                        float* __restrict__ frames, int M, int K, int Nout, float limit, int* flag) {
+    constexpr int NS = 5;
+    __shared__ __attribute__((aligned(16))) f16x8 lds[2 * 4 * NS * 64];       // this workgroup's 128 columns of the bank
+    __shared__ __attribute__((aligned(16))) f16x8 lds0[2 * 4 * NS * 64];      // dense, staged as the condition GEMM stages it (n0 = 0)
+    __shared__ __attribute__((aligned(16))) float ct[4][32 * kCtStride];      // per wave: c of the row tile in hand
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int n0 = blockIdx.y * 128;
+    for (int item = tid; item < 128 * NS * 2; item += 256) {
+        const int c = item & 127, sh = item >> 7, ss = sh >> 1, hh = sh & 1;
+        float v[8], v0[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * ss + 8 * hh + q;
+            v[q] = (k < K && n0 + c < Nout) ? w[(size_t)k * Nout + n0 + c] : 0.f;
+            v0[q] = (k < K0 && c < K) ? w0[(size_t)k * K + c] : 0.f;
+        }
+        f16x8 hi, lo;
+        split8m(v, hi, lo);
+        const int unit = ((c >> 5) * NS + ss) * 64 + hh * 32 + (c & 31);
+        lds[unit] = hi;
+        lds[4 * NS * 64 + unit] = lo;
+        split8m(v0, hi, lo);
+        lds0[unit] = hi;
+        lds0[4 * NS * 64 + unit] = lo;
+    }
+    __syncthreads();
+    const f16x8* AH = lds;
+    const f16x8* AL = lds + 4 * NS * 64;
+    const f16x8* A0H = lds0;
+    const f16x8* A0L = lds0 + 4 * NS * 64;
+    float* const ctw = ct[wave];
+    const int row_tiles = (M + 31) / 32;
+    for (int rt = blockIdx.x * 4 + wave; rt < row_tiles; rt += gridDim.x * 4) {
+        const int m = rt * 32 + j;
+        const bool mvalid = m < M;
+        const int mc = mvalid ? m : M - 1;
+        f16x8 bh[NS], bl[NS];
+        // ---- c = relu(mel @ dense) for the 32 rows of this tile (linear_split_kernel<5> on x0, relu = 1, bias = NULL) ----------
+        bool bad = false;
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int k = 16 * ss + 8 * h + 4 * g;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (k < K0) t = *reinterpret_cast<const f32x4*>(x0 + (size_t)mc * K0 + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[4 * g + e] = t[e];
+                    bad = bad || !(fabsf(t[e]) <= limit);
+                }
+            }
+            split8m(v, bh[ss], bl[ss]);
+        }
+        if (flag && bad) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        f32x16 acc0[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[it][r] = 0.f;
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            f16x8 ah[3], al[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                ah[it] = A0H[(it * NS + ss) * 64 + lane];
+                al[it] = A0L[(it * NS + ss) * 64 + lane];
+            }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                acc0[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ss], ah[it], acc0[it], 0, 0, 0);
+                acc0[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ss], ah[it], acc0[it], 0, 0, 0);
+                acc0[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ss], al[it], acc0[it], 0, 0, 0);
+            }
+        }
+        // lane (j, h) holds column 32 it + j of the rows 8 (r >> 2) + 4 h + (r & 3): into the wave's LDS tile [row][column]
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int n = 32 * it + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = 8 * (r >> 2) + 4 * h + (r & 3);
+                const float v = fmaxf(acc0[it][r], 0.f);
+                if (n < K) {
+                    ctw[ml * kCtStride + n] = v;
+                    const int mr = rt * 32 + ml;
+                    if (frames && blockIdx.y == 0 && mr < M) __hip_atomic_store(&frames[(size_t)mr * K + n], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (same wave writes and reads: program order through the LDS queue)
+        // ---- P tile = c @ bank block + bias (linear_split_kernel<5> on c) --------------------------------------------------------
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int k = 16 * ss + 8 * h + 4 * g;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (k < K) t = *reinterpret_cast<const f32x4*>(&ctw[j * kCtStride + k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = t[e];
+            }
+            split8m(v, bh[ss], bl[ss]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile is free for the next iteration's writes)
+        f32x16 acc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = n0 + 32 * it + j;
+            const float bv = (bias && n < Nout) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][r] = bv;
+        }
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                ah[it] = AH[(it * NS + ss) * 64 + lane];
+                al[it] = AL[(it * NS + ss) * 64 + lane];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ss], ah[it], acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ss], ah[it], acc[it], 0, 0, 0);
+                acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ss], al[it], acc[it], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = n0 + 32 * it + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = rt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (mr < M && n < Nout) __hip_atomic_store(&y[(size_t)mr * Nout + n], acc[it][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // models.py:131-133: out[n,t,:] = frames[n,(t+offset)/hop,:]
 __global__ void upsample_repeat_kernel(const float* __restrict__ frames, float* __restrict__ out, int N, int t_mel,
                                        int C4, int T, int hop, int offset) {
@@ -499,6 +654,24 @@ int pwv_linear_split_f32(const float* x, const float* w, const float* bias, floa
         hipLaunchKernelGGL((linear_split_kernel<5>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
     else
         hipLaunchKernelGGL((linear_split_kernel<8>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_cond_project_f32(const float* mel, const float* dense, int n_mels, const float* bank_w, const float* bank_b, float* frames,
+                         float* P, int M, int C, int Nout, float limit, int* range_flag, pwv_stream_t stream) {
+    PWV_CHECK_ARG(mel && dense && bank_w && P, "pwv_cond_project_f32: NULL pointer");
+    PWV_CHECK_ARG(M >= 0 && n_mels >= 8 && n_mels % 8 == 0 && n_mels <= 80 && C >= 8 && C % 8 == 0 && C <= 80,
+                  "pwv_cond_project_f32: n_mels and C must be multiples of 8 in [8, 80], got %d / %d", n_mels, C);
+    PWV_CHECK_ARG(Nout >= 4 && Nout % 4 == 0, "pwv_cond_project_f32: Nout must be a multiple of 4, got %d", Nout);
+    if (M == 0) return PWV_OK;
+    const unsigned gy = (unsigned)((Nout + 127) / 128);
+    unsigned gx = (unsigned)((M + 127) / 128);
+    const unsigned cap = (1024u + gy - 1) / gy;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(cond_proj_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, mel, dense, n_mels, bank_w, bank_b, P, frames, M, C, Nout,
+                       range_flag ? limit : 3.0e38f, range_flag);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

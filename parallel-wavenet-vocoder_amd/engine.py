@@ -724,24 +724,22 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
 _bank_cache = {}      # tuple of plan ids -> (plans (kept alive), concatenated proj_w [K, total], proj_b [total], column offsets)
 
 
-def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
-    """The frame-rate projections P of EVERY net of a forward (all flows) as one GEMM: P depends on the mel frames only,
-    not on a flow's input, so none of it has to sit between two flows (per flow that was two small launches plus their
-    cross-stream dependencies on the critical path).  The result is attached to the RepeatedCondition; run_nets picks its
-    nets' column blocks out of it (row stride = all columns).  Nets that cannot use it (not fused-capable, a different
-    arithmetic after the range fallback) simply project for themselves as before."""
-    if not HOIST_P or not isinstance(cond, RepeatedCondition) or not nets:
-        return
-    prec = PRECISIONS[precision or DEFAULT_PRECISION]
+FUSE_PROLOGUE = os.environ.get('PWV_FUSE_PROLOGUE', '1') != '0'      # 'repeat' conditioning: mel range check + dense/relu + the projection GEMM as ONE launch (pwv_cond_project_f32)
+FUSE_PROLOGUE_MAX_FRAMES = 1 << 30 # (frames = N * t_mel up to which the fused launch is taken; bit-identical either way)
+
+
+def _projection_bank(nets: Sequence, channels: int, prec: int):
+    """(plans, [C, total] weights, [total] biases, column offsets) of the one projection GEMM of a forward, or None when fewer than
+    two nets can share it (not fused-capable, another arithmetic after the range fallback)."""
     for _ in range(2):
         # (a first forward creates its variables while the plans are built, and every new variable outdates the plans
         # made before it: plan again once the store has stopped changing, so that run_nets finds these very plans)
         versions = [net.store.version for net in nets]
         plans = []
         for net in nets:
-            if not getattr(net, 'fused_supported', None) or not net.fused_supported(cond):
+            if not getattr(net, 'fused_supported', None) or channels != net.condition_channels:
                 continue
-            if cond.frames.shape[2] != net.condition_channels:
+            if not net.fused_supported(_FrameShape(channels)):
                 continue
             p = get_plan(net, 'frames', prec)
             if prec == _lib.PREC_F16X3 and not (p.f16x3_ok and p.x_limit > 0):
@@ -751,7 +749,7 @@ def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
         if versions == [net.store.version for net in nets]:
             break
     if len(plans) < 2:
-        return
+        return None
     key = tuple(id(p) for p in plans)
     hit = _bank_cache.get(key)
     if hit is None:
@@ -763,11 +761,62 @@ def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
             total += p.proj_w.shape[1]
         hit = (plans, torch.cat([p.proj_w for p in plans], dim=1).contiguous(), torch.cat([p.proj_b for p in plans]).contiguous(), offs)
         _bank_cache[key] = hit
-    _, w_all, b_all, offs = hit
+    return hit
+
+
+class _FrameShape(RepeatedCondition):
+    """(what WaveNet.fused_supported looks at: a frame-rate condition with this many channels)"""
+
+    def __init__(self, channels):
+        self.frames = torch.empty((0, 1, channels))
+        self.hop = self.offset = self.length = 0
+
+
+def project_all(nets: Sequence, cond, precision: Optional[str] = None) -> None:
+    """The frame-rate projections P of EVERY net of a forward (all flows) as one GEMM: P depends on the mel frames only,
+    not on a flow's input, so none of it has to sit between two flows (per flow that was two small launches plus their
+    cross-stream dependencies on the critical path).  The result is attached to the RepeatedCondition; run_nets picks its
+    nets' column blocks out of it (row stride = all columns).  Nets that cannot use it (not fused-capable, a different
+    arithmetic after the range fallback) simply project for themselves as before."""
+    if not HOIST_P or not isinstance(cond, RepeatedCondition) or not nets or getattr(cond, 'proj_bank', None) is not None:
+        return
+    prec = PRECISIONS[precision or DEFAULT_PRECISION]
+    bank = _projection_bank(nets, cond.frames.shape[2], prec)
+    if bank is None:
+        return
+    plans, w_all, b_all, offs = bank
     n, frames, c = cond.frames.shape
     f2d = _require_cuda_f32(cond.frames, 'frames').reshape(n * frames, c)
     p_all = linear_op(f2d, w_all, b_all, relu=False, precision=precision or DEFAULT_PRECISION)
     cond.proj_bank = {id(p): p_all[:, o:o + p.proj_w.shape[1]] for p, o in zip(plans, offs)}
+
+
+def repeat_condition_with_projections(nets: Sequence, melspec: torch.Tensor, dense: torch.Tensor, hop: int, length: int,
+                                      precision: Optional[str], mel_limit: Optional[float]):
+    """The prologue of a 'repeat'-conditioned forward as ONE launch (pwv_cond_project_f32): the range check of the mel, the
+    frame-rate condition relu(mel @ dense) (models.py:128-130) and the projections of every net (project_all) -- bit-identical to
+    the three launches it replaces.  Returns the RepeatedCondition with its projection bank attached, or None when the shape is
+    outside the fused kernel's (the caller then takes the separate launches)."""
+    name = precision or DEFAULT_PRECISION
+    if not (FUSE_PROLOGUE and HOIST_P) or name == 'f32' or not nets:
+        return None
+    n, t_mel, n_mels = melspec.shape
+    c = dense.shape[1]
+    if n_mels % 8 or c % 8 or n_mels > 80 or c > 80 or n * t_mel > FUSE_PROLOGUE_MAX_FRAMES:
+        return None
+    bank = _projection_bank(nets, c, PRECISIONS[name])
+    if bank is None:
+        return None
+    plans, w_all, b_all, offs = bank
+    m = n * t_mel
+    frames = torch.empty((n, t_mel, c), dtype=torch.float32, device=melspec.device)
+    p_all = torch.empty((m, w_all.shape[1]), dtype=torch.float32, device=melspec.device)
+    flag = range_flag_ptr() if (name == 'f16x3' and mel_limit is not None) else None
+    check(_lib.lib().pwv_cond_project_f32(_ptr(melspec), _ptr(dense), n_mels, _ptr(w_all), _ptr(b_all), _ptr(frames), _ptr(p_all), m, c,
+                                          w_all.shape[1], float(mel_limit or 0.0), flag, _stream()), 'pwv_cond_project_f32')
+    cond = RepeatedCondition(frames, hop, hop // 2, length)
+    cond.proj_bank = {id(p): p_all[:, o:o + p.proj_w.shape[1]] for p, o in zip(plans, offs)}
+    return cond
 
 
 def run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str] = None,

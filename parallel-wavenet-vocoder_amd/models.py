@@ -78,13 +78,6 @@ class IAFVocoder(object):
         """models.py:23-78: condition, then the flows; only enqueues."""
         shared = bool(hp.model.get('shared_nets', False))
         with variable_scope(name):
-            with variable_scope('cond'):
-                condition = self._condition(melspec, is_training, strides=[4, 4, 5], store=store, precision=precision)   # (n, t, h)
-                if hp.model.normalize_cond and condition is not None:
-                    if isinstance(condition, RepeatedCondition):
-                        condition = condition.materialize()
-                    with variable_scope('normalize'):
-                        condition = normalize(condition, is_training, hp.model.normalize_cond, store=store)
             flows = []
             for i in range(hp.model.n_iaf):
                 with variable_scope('iaf{}'.format(i)):
@@ -110,8 +103,18 @@ class IAFVocoder(object):
                         shifter = WaveNet(quantization_channels=1, name='shifter', **kwargs)
                         iaf = LinearIAFLayer(batch_size=hp.train.batch_size, scaler=scaler, shifter=shifter)
                     flows.append(iaf)
+            all_nets = [net for iaf in flows for net in iaf.nets()]
+            with variable_scope('cond'):
+                # (the flows are set up first -- that opens no variable scope of theirs, models.py:26-29 stays ahead of :36-67 in the
+                # variable order -- so that the one-launch prologue can project for all of them)
+                condition = self._condition(melspec, is_training, strides=[4, 4, 5], store=store, precision=precision, nets=all_nets)   # (n, t, h)
+                if hp.model.normalize_cond and condition is not None:
+                    if isinstance(condition, RepeatedCondition):
+                        condition = condition.materialize()
+                    with variable_scope('normalize'):
+                        condition = normalize(condition, is_training, hp.model.normalize_cond, store=store)
             # the frame-rate projections of every net depend on the mel only: one GEMM for all flows, ahead of the first
-            engine.project_all([net for iaf in flows for net in iaf.nets()], condition, precision=precision)
+            engine.project_all(all_nets, condition, precision=precision)
             for i, iaf in enumerate(flows):
                 input = iaf(input, condition)  # (n, t, h)
                 # normalization (identity at the default hparams), models.py:70
@@ -140,7 +143,7 @@ class IAFVocoder(object):
         return self._mel_limit_val
 
     # -- condition upsampling (models.py:105-136) ----------------------------------------------------
-    def _condition(self, melspec, is_training, strides, store, precision=None):
+    def _condition(self, melspec, is_training, strides, store, precision=None, nets=None):
         """The condition in the form the kernels want: a lazy RepeatedCondition for 'repeat'
         (projected at frame rate inside the nets), a materialised [N, T, C] tensor for
         'transposed_conv', None otherwise."""
@@ -181,7 +184,14 @@ class IAFVocoder(object):
             return engine.crop_time_op(cond, length - hop, hop // 2)            # models.py:124
         elif method == 'repeat':
             w = get_variable('dense', [1, n_mels, C], store=store)
-            if (precision or engine.DEFAULT_PRECISION) == 'f16x3':
+            split = (precision or engine.DEFAULT_PRECISION) == 'f16x3'
+            if nets and not hp.model.normalize_cond:
+                # range check + dense / relu + the projections of every net of the forward: ONE launch (bit-identical to the three)
+                fused = engine.repeat_condition_with_projections(nets, melspec, w[0], hop, self.length, precision,
+                                                                 self._mel_limit([w[0]], store) if split else None)
+                if fused is not None:
+                    return fused
+            if split:
                 engine.range_check_op(melspec, self._mel_limit([w[0]], store))
             frames = engine.linear_op(melspec.reshape(n * t_mel, n_mels), w[0], None, relu=True,
                                       precision=precision)                              # models.py:128-130

@@ -40,7 +40,8 @@ class VariableStore:
         self.restored = set()                       # names set from a checkpoint / dict (what tf.train.Saver.restore covered)
         self.restored_without_shadow = set()        # ... of those, under use_ema, the ones whose shadow the checkpoint lacks
         self.left_at_init = set()                   # non-trainable variables a use_ema restore deliberately did not touch
-        self._ema_restores = 0                      # load_dict(use_ema=True) calls so far
+        self._last_restore_ema = False              # the mode of the MOST RECENT load_dict (what not_restored() answers for)
+        self._warned_left_at_init = False
 
     # -- tf.get_variable -------------------------------------------------------------------
     def get_variable(self, name: str, shape: Sequence[int], initializer: Optional[str] = None) -> torch.Tensor:
@@ -82,11 +83,19 @@ class VariableStore:
         var_list holds tf.trainable_variables('iaf_vocoder') and nothing else, so the moving statistics of a batch norm keep
         what global_variables_initializer gave them (zeros / ones, generate.py:56).  Returns the number of variables set."""
         loaded = 0
-        self._ema_restores += 1 if use_ema else 0
+        self._last_restore_ema = bool(use_ema)
+        if not use_ema:
+            self.left_at_init.clear()               # (a plain restore covers the non-trainable variables too: judge it on its own)
         names = set(k[:-len(EMA_SUFFIX)] if k.endswith(EMA_SUFFIX) else k for k in weights)
         for name in sorted(names):
             if use_ema and not is_trainable(name.split(':')[0]):
                 self.left_at_init.add(name.split(':')[0])
+                if not self._warned_left_at_init:
+                    self._warned_left_at_init = True
+                    import warnings
+                    warnings.warn("pwv: a use_ema restore sets trainable variables only (generate.py:57-63); non-trainable ones such as %s keep "
+                                  "their initial values -- a 'bn' model then normalises with mean 0 / variance 1, exactly like the reference"
+                                  % name.split(':')[0])
                 continue
             key = name + EMA_SUFFIX if (use_ema and name + EMA_SUFFIX in weights) else name
             if key not in weights:
@@ -128,11 +137,9 @@ class VariableStore:
 
     def not_restored(self):
         """Model variables that exist but were never set from a checkpoint (i.e. carry their random initialisation) although
-        the restore should have covered them.  The non-trainable ones a use_ema restore leaves alone like the reference
-        (load_dict) are not listed -- nor are non-trainable variables at all once such a restore has happened (the reference's
-        Saver does not look for them, generate.py:57-63)."""
-        ema_restore = bool(self.left_at_init) or bool(self._ema_restores)
-        return sorted(k for k in self.vars if k not in self.restored and not (ema_restore and not is_trainable(k)))
+        the MOST RECENT restore should have covered them.  After a use_ema restore the non-trainable ones are not listed (the
+        reference's Saver does not look for them, generate.py:57-63); after a plain restore (Saver with var_list=None) they are."""
+        return sorted(k for k in self.vars if k not in self.restored and not (self._last_restore_ema and not is_trainable(k)))
 
     def save_npz(self, path: str) -> None:
         np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.vars.items()})

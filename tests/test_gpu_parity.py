@@ -418,6 +418,7 @@ def test_one_projection_gemm_for_all_flows_is_bit_identical(gpu, precision, monk
         return real(x2d, w, b, relu, precision=precision)
     monkeypatch.setattr(engine, 'linear_op', spy)
     monkeypatch.setattr(engine, 'HOIST_P', True)
+    monkeypatch.setattr(engine, 'FUSE_PROLOGUE', False)
     a = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     hoisted = [s for s in seen if s[1] == 128 * 2 * (3 + 4 + 1)]
     assert len(hoisted) == 1 and not [s for s in seen if s[1] in (128 * 3, 128 * 4, 128)], seen
@@ -425,6 +426,48 @@ def test_one_projection_gemm_for_all_flows_is_bit_identical(gpu, precision, monk
     b = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
     assert np.array_equal(a, b)
     assert np.abs(a - O.iaf_vocoder_forward(weights, mel, z, cfg)).max() <= TOL_F32
+    # round 5: range check + dense / relu + that GEMM as ONE launch (pwv_cond_project_f32; split-fp16 arithmetic only) -- the same bits
+    # again, and none of the three launches it replaces is enqueued
+    monkeypatch.setattr(engine, 'HOIST_P', True)
+    monkeypatch.setattr(engine, 'FUSE_PROLOGUE', True)
+    del seen[:]
+    c = run_vocoder_hip(cfg, weights, mel, z, gpu, precision=precision)
+    assert np.array_equal(a, c)
+    if precision == 'f16x3':
+        assert not seen, seen
+
+
+def test_one_launch_prologue_is_bit_identical_and_guards_the_range(gpu):
+    """pwv_cond_project_f32 against the launches it replaces, through the C ABI: frames = relu(mel @ dense) (models.py:128-130) and
+    P = frames @ bank + bias, ragged row counts (row tiles that end inside a tile, fewer rows than one tile), column counts off the
+    128-column blocks; and the range guard: one value beyond the limit / one NaN anywhere in the mel raises the flag."""
+    import ctypes
+    import torch
+    from pwv_amd import _lib, engine
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    for m, nout in ((201, 15360), (33, 128 * 9), (7, 260), (2001, 128 * 18)):
+        mel = (torch.rand((m, 80), generator=g) * 2 - 1).to(gpu)
+        dense = (torch.randn((80, 80), generator=g) * 0.2).to(gpu)
+        bank_w = (torch.randn((80, nout), generator=g) * 0.3).to(gpu)
+        bank_b = torch.randn((nout,), generator=g).to(gpu)
+        want_f = engine.linear_op(mel, dense, None, relu=True, precision='f16x3')
+        want_p = engine.linear_op(want_f, bank_w, bank_b, relu=False, precision='f16x3')
+        frames = torch.full((m, 80), float('nan'), device=gpu)
+        P = torch.full((m, nout), float('nan'), device=gpu)
+        w = engine.current_words()
+        for poison, raised in ((None, False), ((m // 2, 17, 3.0e4), True), ((m - 1, 79, float('nan')), True)):
+            x = mel.clone()
+            if poison:
+                x[poison[0], poison[1]] = poison[2]
+            w.range = 0
+            engine.check(lib.pwv_cond_project_f32(x.data_ptr(), dense.data_ptr(), 80, bank_w.data_ptr(), bank_b.data_ptr(), frames.data_ptr(),
+                                                  P.data_ptr(), m, 80, nout, 1.0e4, engine.range_flag_ptr(), engine._stream()), 'pwv_cond_project_f32')
+            torch.cuda.synchronize()
+            assert bool(w.range) == raised, (m, nout, poison)
+            w.range = 0
+            if not poison:
+                assert torch.equal(frames, want_f) and torch.equal(P, want_p), (m, nout)
 
 
 def test_plain_c_client_runs(gpu, tmp_path):
