@@ -725,7 +725,11 @@ _bank_cache = {}      # tuple of plan ids -> (plans (kept alive), concatenated p
 
 
 FUSE_PROLOGUE = os.environ.get('PWV_FUSE_PROLOGUE', '1') != '0'      # 'repeat' conditioning: mel range check + dense/relu + the projection GEMM as ONE launch (pwv_cond_project_f32)
-FUSE_PROLOGUE_MAX_FRAMES = 1 << 30 # (frames = N * t_mel up to which the fused launch is taken; bit-identical either way)
+# ... where it pays.  The fused launch recomputes the condition per 128-column block of the bank and holds 113 KB of LDS (one
+# workgroup per CU): same box, fused vs three launches (profiles/r05_ab_experiments.md): C1 (201 frames x 2048 columns) -5 %,
+# default model at 16000 samples (201 x 15360) level, C3 (2001 x 15360) +1.3 %, C4 +1 %.  Bit-identical either way, so the choice may
+# depend on the size: frames x columns up to this many outputs take the one launch.
+FUSE_PROLOGUE_MAX_OUTPUTS = 1 << 21
 
 
 def _projection_bank(nets: Sequence, channels: int, prec: int):
@@ -802,13 +806,15 @@ def repeat_condition_with_projections(nets: Sequence, melspec: torch.Tensor, den
         return None
     n, t_mel, n_mels = melspec.shape
     c = dense.shape[1]
-    if n_mels % 8 or c % 8 or n_mels > 80 or c > 80 or n * t_mel > FUSE_PROLOGUE_MAX_FRAMES:
+    if n_mels % 8 or c % 8 or n_mels > 80 or c > 80:
         return None
     bank = _projection_bank(nets, c, PRECISIONS[name])
     if bank is None:
         return None
     plans, w_all, b_all, offs = bank
     m = n * t_mel
+    if m * w_all.shape[1] > FUSE_PROLOGUE_MAX_OUTPUTS:
+        return None
     frames = torch.empty((n, t_mel, c), dtype=torch.float32, device=melspec.device)
     p_all = torch.empty((m, w_all.shape[1]), dtype=torch.float32, device=melspec.device)
     flag = range_flag_ptr() if (name == 'f16x3' and mel_limit is not None) else None

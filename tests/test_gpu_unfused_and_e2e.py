@@ -83,14 +83,14 @@ def test_normalisers_with_trained_statistics(gpu, method, skip):
     # the oracle really used the randomised parameters (guards against a naming mismatch silently meaning "identity")
     assert np.abs(want - O.iaf_vocoder_forward(O.init_weights(cfg, seed=2), mel, z, cfg)).max() > 1e-3
     log = []
-    orig = engine.run_nets
-    engine.run_nets = lambda *a, **k: (log.append(1), orig(*a, **k))[1]
+    orig = engine._run_nets
+    engine._run_nets = lambda *a, **k: (log.append(1), orig(*a, **k))[1]
     try:
         got = model(None, mel_t, is_training=False, z=z_t)
         model.verify()
     finally:
-        engine.run_nets = orig
-    assert (len(log) == cfg.n_iaf) == (method == 'bn')       # 'bn': one fused run_nets per flow; 'in': the un-fused path
+        engine._run_nets = orig
+    assert (len(log) == cfg.n_iaf) == (method == 'bn')       # 'bn': one fused run_flow / run_nets per flow; 'in': the un-fused path
     err = np.abs(got.cpu().numpy() - want).max()
     assert err <= 5e-5 * max(1.0, np.abs(want).max()), err
     if method == 'bn':
