@@ -233,6 +233,7 @@ class WaveNet(object):
         enqueues and the outermost call verifies."""
         if self.fused_supported(condition_batch):
             return engine.verified_call(lambda prec: engine.run_nets([self], input_batch, condition_batch, precision=prec or self.precision)[0], verify)
+        _note_unfused(self)
         return self._call_unfused(input_batch, condition_batch)
 
     def _call_unfused(self, input_batch, condition_batch):
@@ -301,6 +302,22 @@ class WaveNet(object):
         if self.use_biases:
             c2 = bias_add(c2, hv['postprocess2_bias'])
         return c2
+
+
+_unfused_noted = set()
+
+
+def _note_unfused(net) -> None:
+    """Said once per architecture: this net is outside the fused kernels' shape and runs on the composed path."""
+    key = (net.filter_width, net.residual_channels, net.dilation_channels, net.skip_channels, net.out_channels, net.condition_channels, net.normalize or '')
+    if key not in _unfused_noted:
+        _unfused_noted.add(key)
+        import warnings
+        warnings.warn('pwv-info: WaveNet %s (W=%d R=%d D=%d S=%d Q=%d C=%s normalize=%r) is outside the shape of the fused kernels (W=2, R=D=64, S=128, '
+                      'Q<=4, C=80 per sample or C%%8==0 at frame rate; hparams/default.yaml:22-26): it runs on the composed path -- every op a HIP '
+                      'kernel, same math (modules.py:129-259), about 12 launches per layer instead of one launch per flow'
+                      % (net.full_scope, net.filter_width, net.residual_channels, net.dilation_channels, net.skip_channels, net.out_channels,
+                         net.condition_channels, net.normalize))
 
 
 class LinearIAFLayer(object):
