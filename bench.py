@@ -50,7 +50,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LAYER_FLOP_PER_SAMPLE = 2 * (2 * 64 * 128 + 64 * 64)      # 40960
 LAYER_BYTES_PER_SAMPLE = 2 * 64 * 4                       # 512
 
-# what holds the split-fp16 unit body below both nominal roofs (the files are in profiles/ and tools/probes/)
+# what holds the split-fp16 unit body below both nominal roofs (history in HISTORY.md section 4, K1 / K1p; the files are in profiles/ and tools/probes/)
 LIMITER_K1P = ('neither nominal roof binds: by arithmetic intensity (3 x 80 = 240 fp16-FLOP/B < 312) the HBM roof is the nominal one, but the unit body is '
                'bound by ISSUE and CLOCK.  (1) issue: MFMA and VALU instructions of the two waves of a SIMD issue serially (tools/probes/coissue.hip: '
                '32 cycles per MFMA + 2-2.7 per VALU instruction, same counts on 8 workgroups at 2.4 GHz), so 120 MFMA + ~790 VALU + 96 transcendentals per '
@@ -136,10 +136,11 @@ def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process'):
     rates, fwd = {}, {}
     for k in sweep:
         f = fwd[k] = ChunkedForward(w, case_cfg, chunk, k, mode)
-        mel, z = O.synthetic_inputs(1, chunk * 2 * k, case_cfg)
+        per = 2 if k <= 16 else 1                                       # (chunks per worker: keeps every point of the sweep to a second or two)
+        mel, z = O.synthetic_inputs(1, chunk * per * k, case_cfg)
         t0 = time.perf_counter()
         f(mel, z)
-        rates[k] = chunk * 2 * k / (time.perf_counter() - t0)
+        rates[k] = chunk * per * k / (time.perf_counter() - t0)
         if k != 1:
             f.close()
     best = max(rates, key=lambda k: rates[k])
@@ -165,7 +166,7 @@ def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process'):
             'physical_cores': phys, 'logical_cpus': logical, 'cpu': cpu_model, 'chunk_samples': chunk, 'workers': mode,
             'sample': 'same model, 1 utterance x %d samples (%.1f s wall on %d cores), torch-CPU fp32 restatement of the reference math '
                       '(oracle/torch_cpu.py, conditioning per sample as written) evaluated in %d-sample time chunks with the flow\'s look-back '
-                      'recomputed, one chunk per core at a time (%s pool); sweep on 2k chunks for k in %s, best = %d; value_1thread is the k = 1 point'
+                      'recomputed, one chunk per core at a time (%s pool); sweep on 2k chunks (k chunks beyond 16 workers) for k in %s, best = %d; value_1thread is the k = 1 point'
                       % (length, dt, best, chunk, mode, sorted(rates), best)}
 
 
@@ -462,8 +463,10 @@ def main():
                 again = int(t.item())
             if not again:
                 return made, elapsed_, out_
-            if not control and not engine.persist_suspended():
-                engine.suspend_persist()          # (the give-up was on another rank: this rank leaves the persistent launches with it)
+            if not control:
+                # bench policy: once any rank has seen a give-up, the whole measurement runs on per-layer launches (the engine's own
+                # policy -- suspend, retry after 16 forwards -- would switch launch paths in the middle of the timed loop)
+                engine.PERSIST = False
             if attempt:
                 raise failed[0] if failed else _lib.PwvPersistError('a persistent launch gave up on another rank, twice')
             sys.stderr.write('%s\nre-timing with per-layer launches\n' % (failed[0] if failed else 'a persistent launch gave up on another rank'))

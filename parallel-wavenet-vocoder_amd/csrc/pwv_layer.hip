@@ -4,7 +4,7 @@
 // (/root/reference/modules.py:185-259) and, per net, the post-processing of
 // WaveNet.__call__ (modules.py:145-165).
 //
-// Design:
+// Design (measured history in HISTORY.md section 4):
 //   * GEMM orientation: MFMA rows = output channels, MFMA columns = time.  A wave owns 32
 //     consecutive samples; lane (t = lane&31, h = lane>>5) owns, of every 64-channel row, the
 //     16-byte chunks at float offsets 8g + 4h -- which is exactly the v_mfma 32x32 C/D layout

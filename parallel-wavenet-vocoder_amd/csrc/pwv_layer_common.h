@@ -158,7 +158,7 @@ __device__ __forceinline__ void fill_lds(float* lds, const float* __restrict__ p
 // 32u .. 32u+31 as [C/4 channel quads][32 rows][4 floats].  A wave owns 32 rows and lane (t, h) owns channel
 // quads 2g + h, so each of its vector loads / stores covers 1 KB of CONTIGUOUS memory (32 rows x 16 B for
 // h = 0, then the same for h = 1).  With plain channels-last rows the same instruction touched 32 B in each of
-// 32 cache lines: measured 64 -> 50 us per layer launch at 160000 rows.
+// 32 cache lines: measured 64 -> 50 us per layer launch at 160000 rows (HISTORY.md section 3).
 // Buffers are padded to whole blocks: tile32_floats(rows, C).
 __host__ __device__ inline size_t tile32_floats(long long rows, int C) { return (size_t)((rows + 31) / 32) * 32 * C; }
 __device__ __forceinline__ size_t tile_off(int row, int quad, int C) {
@@ -166,7 +166,7 @@ __device__ __forceinline__ size_t tile_off(int row, int quad, int C) {
 }
 // Residual-stream stores are WRITE-THROUGH (`sc1`): the line stays valid in the XCD's L2 for the next layer's reads, but
 // it is no longer dirty, so the end-of-kernel release has nothing left to write back -- the ~40 MB a launch stores drain
-// while it computes instead of between it and the dependent launch (measured: -2.6 % per step).  The cache
+// while it computes instead of between it and the dependent launch (measured: -2.6 % per step, HISTORY.md section 4, K1).  The cache
 // policy bits of a store are only reachable through the buffer intrinsics; the descriptor covers exactly the workgroup's
 // own units [u_begin, u_end), so out-of-range offsets are dropped by the hardware.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -3,7 +3,7 @@
 //
 // Why: a per-layer launch of layer_f16x3_kernel pays, besides its steady state, a weight-staging prologue (1.7 us), the
 // first rows' latency (1.3 us), the spread of its workgroups' end times (~8 %: every workgroup waits for the slowest at
-// EVERY layer) and the gap to the dependent launch (1.5 us): ~20 % of a 46 us launch.
+// EVERY layer) and the gap to the dependent launch (1.5 us): ~20 % of a 46 us launch (HISTORY.md section 4, K1p).
 //
 // Round 3 design -- STATIC ownership (the round-2 kernel dealt (layer, unit) tasks out of per-XCD pools with global
 // atomics, recomputed the x[t-d] halo per XCD and was 3 % slower than the launches it replaced):

@@ -57,7 +57,7 @@ FUSE_HEAD = True
 FUSE_TAIL = os.environ.get('PWV_FUSE_TAIL', '1') != '0'      # (PWV_FUSE_TAIL=0: A/B runs of tools/r05_run2.sh)
 HOIST_P = True               # one projection GEMM per forward (project_all); False: every net projects for itself (cross-check in tests)
 # PWV_FOLD_FIRST=0: layer 0 runs its filter|gate GEMM on the rebuilt causal-layer rows (eight MFMA k-steps) instead of on the
-# four scalars they are a function of (one k-step); default: folded.  The only knob that changes bits.
+# four scalars they are a function of (one k-step); default: folded.  The only knob that changes bits (measured in HISTORY.md section 4, K2).
 FOLD_FIRST = os.environ.get('PWV_FOLD_FIRST', '1') != '0'
 # The residual layers of a stack as ONE persistent launch (csrc/pwv_stack_persist.hip, bit-identical results) instead of one
 # launch per layer.  PWV_PERSIST = 0 | 1 | auto (default: wherever the library supports the shape; '1' forces it).

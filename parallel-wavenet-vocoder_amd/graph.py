@@ -1,7 +1,7 @@
 """The forward of an IAFVocoder captured once into a HIP graph and replayed.
 
 The path is 16 dependent kernel launches per forward with the persistent stack launch (~115 on the per-layer path;
-DESIGN.md section 4, "Launch structure"); eager, every one costs a host enqueue and leaves a gap in front of the next
+DESIGN.md section 4, "Launch structure": since round 5 one prologue launch or three plus ONE launch per flow); eager, every one costs a host enqueue and leaves a gap in front of the next
 kernel.  Capturing the stream work (the launches of libpwv_hip.so on torch's current stream and, on the per-layer path,
 on the two per-net side streams with their fork / join events) into one graph removes the host from the loop:
 bit-identical results, 2 % faster at 160000 samples, 12 % at 16000 samples, 37 % for the one-flow configuration

@@ -1,4 +1,4 @@
-"""CPU: the algebra behind the folded layer 0 (pwv_pack_first_fold_f16x3 / _f32, DESIGN.md "Layer 0 folded"), checked with the
+"""CPU: the algebra behind the folded layer 0 (pwv_pack_first_fold_f16x3 / _f32, HISTORY.md section 4 "Layer 0 folded"), checked with the
 oracle's own causal convolutions in fp64.
 
 The causal layer of a scalar-input net is h[t] = x[t-1] w0 + x[t] w1 (modules.py:174-183, filter [2, 1, R], no bias), so the

@@ -5,7 +5,7 @@
 # Each NAME[:DEFINES] becomes tools/abl_so/libpwv_NAME.so, compiled with -DPWV_<define> for every define (default: NAME itself)
 # from a scratch copy of csrc/ with the patch applied (the probes are kept out of the product sources).  Results are WRONG by
 # design for the ABL_* variants; only the step time is of interest.  (Rounds 1-2 used perturb.patch against the per-layer kernel
-# of that time -- ADD_LDS / ADD_MFMA / ADD_VALU / ADD_P2 / ADD_X2 / ABL_NOP / ABL_PMFMA; git history has it.)
+# of that time -- ADD_LDS / ADD_MFMA / ADD_VALU / ADD_P2 / ADD_X2 / ABL_NOP / ABL_PMFMA, HISTORY.md section 4, K1 item 6; git history has it.)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 patchfile=${PATCH:-persist_probes.patch}
