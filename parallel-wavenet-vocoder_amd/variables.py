@@ -152,7 +152,18 @@ class VariableStore:
 
 
 _default_store: Optional[VariableStore] = None
-_scope_stack = []
+# The scope stack is per THREAD, like TensorFlow's (a variable scope belongs to the thread that opened it): two threads that
+# run forwards side by side must not see each other's `iaf_vocoder/iaf2/...` prefixes -- with a process-wide stack they read and
+# created each other's variables (found by tests/test_safe_call.py::test_two_threads_on_two_streams_..., round 5).
+import threading as _threading
+_scopes = _threading.local()
+
+
+def _stack() -> list:
+    st = getattr(_scopes, 'stack', None)
+    if st is None:
+        st = _scopes.stack = []
+    return st
 
 
 def get_default_store() -> VariableStore:
@@ -182,23 +193,23 @@ def variable_scope(name: str, absolute: bool = False):
     """tf.variable_scope: names created inside get the prefix ``<name>/``.  ``absolute`` replaces the
     enclosing scopes instead of nesting in them (re-entering a captured scope, as TF does when a
     VariableScope object is passed)."""
-    global _scope_stack
     if absolute:
-        saved, _scope_stack = _scope_stack, [name]
+        saved, _scopes.stack = _stack(), [name]
         try:
             yield
         finally:
-            _scope_stack = saved
+            _scopes.stack = saved
         return
-    _scope_stack.append(name)
+    st = _stack()
+    st.append(name)
     try:
         yield
     finally:
-        _scope_stack.pop()
+        st.pop()
 
 
 def current_scope() -> str:
-    return '/'.join(s for s in _scope_stack if s)
+    return '/'.join(s for s in _stack() if s)
 
 
 def scoped(name: str) -> str:

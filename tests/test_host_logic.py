@@ -243,3 +243,30 @@ def test_roofline_reproduces_from_the_committed_profiles(case, precision, name):
     assert roof['traffic_measured_in_run'] is False and cp['measured_in_run'] is False      # (provenance: canned, and labelled so)
     assert cp['source'].startswith('profiles/') and not any(k in roof for k in ('frac_rocprof', 'rocprof_kernel_us', 'traffic_source'))
     assert abs(cp['frac_rocprof'] - roof_b['frac']) < 0.08 * roof_b['frac']      # the profiler costs a few per cent, not more
+
+
+def test_variable_scopes_are_per_thread():
+    """tf.variable_scope is thread-local; so is the restatement's (variables.variable_scope).  Two threads that build models side by
+    side must not see each other's prefixes -- with one process-wide stack they read and created each other's variables (a GPU
+    test with two serving threads found it: results off by O(1), round 5)."""
+    import threading
+    from pwv_amd.variables import current_scope, scoped, variable_scope
+    seen, go = {}, threading.Barrier(2)
+
+    def work(tag):
+        with variable_scope('iaf_vocoder'):
+            with variable_scope(tag):
+                go.wait()                      # both threads are inside their scopes now
+                seen[tag] = (current_scope(), scoped('filter'))
+                go.wait()
+            with variable_scope('abs_' + tag, absolute=True):
+                go.wait()
+                seen[tag + '_abs'] = current_scope()
+                go.wait()
+    ts = [threading.Thread(target=work, args=(t,)) for t in ('a', 'b')]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen == {'a': ('iaf_vocoder/a', 'iaf_vocoder/a/filter'), 'b': ('iaf_vocoder/b', 'iaf_vocoder/b/filter'),
+                    'a_abs': 'abs_a', 'b_abs': 'abs_b'} and current_scope() == ''

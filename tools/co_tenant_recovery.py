@@ -64,6 +64,8 @@ def main():
     ap.add_argument('--before', type=int, default=30)
     ap.add_argument('--after-seconds', type=float, default=6.0)
     ap.add_argument('--length', type=int, default=160000)
+    ap.add_argument('--poke', type=int, default=0, help='no co-tenant: write the give-up word from the host behind this many forwards (what a launch '
+                                                         'that gave up would do), and again right after the suspension ends (the back-off doubles)')
     a = ap.parse_args()
     if a.tenant:
         return tenant(a.tenant_seconds, a.length)
@@ -85,6 +87,28 @@ def main():
         repaired = any('gave up' in str(x.message) for x in w)
         log.append((time.time() - t0, 'per-layer' if suspended else 'persistent', ms, repaired))
 
+    if a.poke:
+        real, state = engine._run_stack_persist, {'n': 0, 'at': [a.poke, a.poke + 1 + engine.PERSIST_RETRY_AFTER + 1]}
+
+        def spy(*args, **kw):
+            r = real(*args, **kw)
+            if state['at'] and len(log) >= state['at'][0]:
+                state['at'].pop(0)
+                engine.poke_persist_status(4)
+            return r
+        engine._run_stack_persist = spy
+        for _ in range(a.poke + 4 * engine.PERSIST_RETRY_AFTER + 40):
+            one()
+        prev = None
+        for k, (t, path, ms, rep) in enumerate(log):
+            key = (path, rep)
+            if key != prev:
+                print('forward %4d  %-10s %s  (%.2f ms)' % (k, path, 'GIVE-UP (poked), repaired inside the call' if rep else '', ms))
+                prev = key
+        sus = [k for k, x in enumerate(log) if x[1] == 'per-layer']
+        print('forwards %d, give-ups %d, forwards on per-layer launches %d (first pause %d, second %d); back on persistent launches at the end: %s'
+              % (len(log), sum(1 for x in log if x[3]), len(sus), engine.PERSIST_RETRY_AFTER, 2 * engine.PERSIST_RETRY_AFTER, log[-1][1] == 'persistent'))
+        return
     for _ in range(a.before):
         one()
     proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--tenant', '--tenant-seconds', str(a.tenant_seconds), '--length', str(a.length)])
