@@ -106,8 +106,9 @@ def main():
                 print('forward %4d  %-10s %s  (%.2f ms)' % (k, path, 'GIVE-UP (poked), repaired inside the call' if rep else '', ms))
                 prev = key
         sus = [k for k, x in enumerate(log) if x[1] == 'per-layer']
-        print('forwards %d, give-ups %d, forwards on per-layer launches %d (first pause %d, second %d); back on persistent launches at the end: %s'
-              % (len(log), sum(1 for x in log if x[3]), len(sus), engine.PERSIST_RETRY_AFTER, 2 * engine.PERSIST_RETRY_AFTER, log[-1][1] == 'persistent'))
+        print('forwards %d, give-ups %d, forwards on per-layer launches %d (engine.PERSIST_RETRY_AFTER = %d per pause; a give-up on the first try '
+              'after a pause doubles it); back on persistent launches at the end: %s'
+              % (len(log), sum(1 for x in log if x[3]), len(sus), engine.PERSIST_RETRY_AFTER, log[-1][1] == 'persistent'))
         return
     for _ in range(a.before):
         one()
