@@ -72,6 +72,7 @@ struct PersistParams {
     long long packed_stride;
     int proj_row_stride;
     int G, N, T, n_layers, units, per_wg, nwg, last_wg, reach_wgs, xcd_map, rot;
+    int all_wt;                            // != 0: every ring store is write-through (a layer's rows exceed the L2s: see the launcher)
     int cond_hop, cond_offset, cond_frames;
     unsigned T_magic, T_shift, hop_magic, hop_shift;
     int dil[kMaxPLayers];
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             {
                 const int so = out_soff(0);
                 const int oo = toff(row);
-                const bool shared = u + ((dn + 31) >> 5) >= u_end;      // units the right neighbour reads in layer 1: write-through
+                const bool shared = p.all_wt || u + ((dn + 31) >> 5) >= u_end;      // units the right neighbour reads in layer 1: write-through
                 if (valid) {
                     if (shared) {
 #pragma unroll
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             const int oo = toff(row);
             // units the right neighbour reads as x[t-d] in the next layer are stored write-through
             const int dn = dil_next(j);
-            const bool shared = u + ((dn + 31) >> 5) >= u_end;
+            const bool shared = p.all_wt || u + ((dn + 31) >> 5) >= u_end;
             if (valid) {
                 if (shared) {
 #pragma unroll
@@ -1200,6 +1201,12 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     p.last_wg = pl.last_wg;
     p.reach_wgs = pl.reach_wgs;
     p.xcd_map = pl.xcd_map;
+    // Ring stores that no other workgroup reads are plain (the line stays in the XCD's L2 for the next layer's loads) -- as long as a
+    // layer's rows FIT the L2s (8 x 4 MB).  Beyond that the lines are evicted before they are re-read anyway, and what is still
+    // dirty when the launch ends (dead data: the ring is scratch) is written back between this launch and the next one: all
+    // write-through measures -0.8 % / -0.2 % on C3 on two boxes (82 MB per layer), -0.2 % on C4, but +5 % on C1 and level at 16000 rows
+    // (4 - 8 MB per layer) (profiles/r05_ab_experiments.md, r05_h / r05_i).  Same bits either way.
+    p.all_wt = (long long)a->N * a->T * a->G * 256 > (32ll << 20) ? 1 : 0;
     PWV_CHECK_ARG(a->ring_rotation >= 0 && a->ring_rotation < 3, "pwv_wavenet_stack_persist_f32: ring_rotation must be 0, 1 or 2");
     p.rot = a->ring_rotation;
     p.cond_hop = a->cond_hop;

@@ -63,8 +63,9 @@ FOLD_FIRST = os.environ.get('PWV_FOLD_FIRST', '1') != '0'
 # launch per layer.  PWV_PERSIST = 0 | 1 | auto (default: wherever the library supports the shape; '1' forces it).
 _pm = os.environ.get('PWV_PERSIST', 'auto')
 PERSIST = {'0': False, '1': True}.get(_pm, 'auto')
-PERSIST_AUTO_MAX_ROWS = 600000     # rows (N*T) per launch up to which 'auto' takes the persistent launch: measured on C3's model (round 4, same box,
-                                   # per-layer vs persistent): 160000 rows -5.5 %, 320000 -3.5 %, 480000 -0.6 %, 640000 +0.3 %, 960000 +1.5 % per step
+PERSIST_AUTO_MAX_ROWS = 750000     # rows (N*T) per launch up to which 'auto' takes the persistent launch: measured on C3's model, same box, per-layer vs
+                                   # persistent -- round 4: 160000 rows -5.5 %, 320000 -3.5 %, 480000 -0.6 %, 640000 +0.3 %, 960000 +1.5 % per step; round 5, with
+                                   # the last layer + head + affine riding in the launch: 480000 -0.5 %, 640000 -0.6 %, 960000 +1.1 % (profiles/r05_ab_experiments.md r05_i)
 PERSIST_MIN_UNITS = 0         # short inputs: fewer workgroups rather than ranges below this many units (0 = the library's default, 4)
 PERSIST_MAX_LAYERS = 32       # longest run of layers in one persistent launch (a stack is cut into equal runs that hand the ring on)
 # PWV_ASYNC=1: the reference-shaped calls (IAFVocoder / WaveNet / LinearIAFLayer __call__) only ENQUEUE, like the C ABI; the
