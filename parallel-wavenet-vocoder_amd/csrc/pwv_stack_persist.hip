@@ -94,17 +94,23 @@ struct PersistParams {
 };
 
 // -DPWV_PTRACE: every wave accumulates s_memtime cycles: [0] whole loop, [1] drain at the top, [2] RAW spins, [3] WAR spins,
-// [4] settle (publish / leave / refill), [5] units, [6] tasks that were not prefetched, [7] first task at, [8] last task done at
+// [4] settle (publish / leave / refill), [5] units, [6] tasks that were not prefetched, [7] first task at, [8] last task done at;
+// round 5, phases of a unit of the general loop (PT_PHASE: the time since the previous stamp goes to slot k): [9] top of the unit up
+// to the drain (P row requested, next task located, look-back row split), [10] GEMM1, [11] GEMM2, [12] stores + moving on
 #ifdef PWV_PTRACE
-#define PT_DECL long long pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = 0; (void)pt_t;
+#define PT_DECL long long pt_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = 0, pt_p = 0; (void)pt_t; (void)pt_p;
 #define PT_BEGIN() pt_t = __builtin_amdgcn_s_memtime()
 #define PT_END(k) pt_acc[k] += __builtin_amdgcn_s_memtime() - pt_t
 #define PT_ADD(k, v) pt_acc[k] += (v)
+#define PT_MARK() do { __builtin_amdgcn_sched_barrier(0); pt_p = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PT_PHASE(k) do { __builtin_amdgcn_sched_barrier(0); const long long pt_n = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_n - pt_p; pt_p = pt_n; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PT_DECL
 #define PT_BEGIN() do {} while (0)
 #define PT_END(k) do {} while (0)
 #define PT_ADD(k, v) do {} while (0)
+#define PT_MARK() do {} while (0)
+#define PT_PHASE(k) do {} while (0)
 #endif
 
 // dependency bits of a task: [0] own x[t] rows, [1] [2] x[t-d] rows, [3] this layer's weights resident (RAW side);
@@ -574,6 +580,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     int lv_j = j;                          // layer voff / vneed currently describe
 
     while (u >= 0 && !dead) {
+        PT_MARK();
         // ---- TOP: P row requested; the rows of this unit were requested during the previous one ---------------------------
         int row, rc, nn, t;
         bool valid;
@@ -625,6 +632,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         // drain + publish + leave, behind the first operand work of the unit (the P row and the previous unit's stores land
         // meanwhile); then the verdict on the next task's dependencies
         auto settle_top = [&]() {
+            PT_PHASE(9);
             PT_BEGIN();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PT_END(1);
@@ -632,10 +640,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             if (left_upto < j) leave_layers(j);
             if (u2 >= 0) claim_v = claim();
             PT_ADD(5, 1);
+            PT_MARK();
         };
         // the next task's rows: requested between GEMM1 and GEMM2, in flight under GEMM2 + gating + stores -- if their
         // producers are done (normally they are a layer-sweep old); otherwise behind this unit's stores, after a wait
         auto prefetch_next = [&]() {
+            PT_PHASE(10);
             if (u2 >= 0 && !(bad2 & kRawMask)) {
                 load_x(j2, u2, rxb, rxc);
             } else {      // (ends the old rows' live ranges: without it they would occupy 64 registers through both GEMMs)
@@ -764,6 +774,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 });
         }
         if (dead) break;
+        PT_PHASE(11);
         // ---- stores (after the readers of the ring slot they overwrite are known to be done) -------------------------------
         if (!war_ok) {
             PT_BEGIN();
@@ -813,6 +824,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         j = j2;
         u = u2;
         war_ok = (bad2 & kWarMask) == 0;
+        PT_PHASE(12);
     }
     // the last unit's stores, a refill this wave still owes, and the layers it has not yet counted itself out of
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1083,9 +1095,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     if (p.trace && lane == 0) {
         pt_acc[8] = __builtin_amdgcn_s_memtime();
         pt_acc[0] = pt_acc[8] - pt_start;
-        long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
-        for (int k = 0; k < 10; ++k) tr[k] = pt_acc[k];
-        tr[10] = net; tr[11] = w; tr[12] = dead ? 1 : 0; tr[13] = __builtin_amdgcn_s_memrealtime(); tr[14] = pt_start_rt;
+        long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 24;
+        for (int k = 0; k < 13; ++k) tr[k] = pt_acc[k];
+        tr[16] = net; tr[17] = w; tr[18] = dead ? 1 : 0; tr[19] = __builtin_amdgcn_s_memrealtime(); tr[20] = pt_start_rt;
     }
 #endif
 }

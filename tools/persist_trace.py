@@ -29,7 +29,7 @@ def main():
     x = torch.randn((1, rows, 1), generator=g).to(dev)
     frames = torch.rand((1, rows // hop + 1, 80), generator=g).to(dev)
     cond = engine.RepeatedCondition(frames, hop, hop // 2, rows)
-    trace = torch.zeros((2 * 256 * 8, 16), dtype=torch.int64, device=dev)
+    trace = torch.zeros((2 * 256 * 8, 24), dtype=torch.int64, device=dev)
     os.environ['PWV_PTRACE_PTR'] = str(trace.data_ptr())
     engine.PERSIST = True
     for _ in range(3):
@@ -43,7 +43,7 @@ def main():
     # per wave: [0] loop cycles, [1] drain at the top, [2] RAW spins (incl. the publish in front), [3] WAR spins, [4] settle,
     # [5] units, [6] units whose rows were not prefetched, [7]/[8] first task at / last task done at (s_memtime), [12] gave up
     print('%d waves, units per wave: mean %.1f (min %d, max %d); status %d; waves that gave up: %d'
-          % (len(t), t[:, 5].mean(), t[:, 5].min(), t[:, 5].max(), engine.persist_status(), int(t[:, 12].sum())))
+          % (len(t), t[:, 5].mean(), t[:, 5].min(), t[:, 5].max(), engine.persist_status(), int(t[:, 18].sum())))
     tot = t[:, 0]
     print('loop cycles per wave: mean %.0f, min %.0f, max %.0f; per unit %.0f (steady: two waves share a SIMD)'
           % (tot.mean(), tot.min(), tot.max(), (tot / t[:, 5]).mean()))
@@ -51,18 +51,23 @@ def main():
         print('  %-44s %6.2f %% of the loop (mean %.0f cycles per unit, worst wave %.1f %%)'
               % (name, 100 * t[:, k].sum() / tot.sum(), (t[:, k] / t[:, 5]).mean(), 100 * (t[:, k] / tot).max()))
     print('  units whose rows were NOT prefetched: %.2f %%' % (100 * t[:, 6].sum() / t[:, 5].sum()))
-    t0 = t[:, 14].min()
-    st, en = (t[:, 14] - t0) / 100.0, (t[:, 13] - t0) / 100.0
+    # round 5: where a unit of the general loop spends its time (cycles per unit, means over the waves; [1] [2] [3] are inside [9] / [12])
+    for k, name in ((9, 'top: P row requested, next task located, look-back row split'), (1, 'drain vmcnt(0): the rows, the P row, the previous stores'),
+                    (10, 'GEMM1 (filter|gate, K = 128; gate of pair 0)'), (11, 'GEMM2 (dense; gate of pair 1; next rows requested)'),
+                    (12, 'stores + moving on (incl. the waits for the next task)')):
+        print('  phase %-68s %7.0f cycles per unit' % (name, (t[:, k] / t[:, 5]).mean()))
+    t0 = t[:, 20].min()
+    st, en = (t[:, 20] - t0) / 100.0, (t[:, 19] - t0) / 100.0
     print('loop start %.1f .. %.1f us, loop end %.1f .. %.1f us (chip-wide 100 MHz clock)' % (st.min(), st.max(), en.min(), en.max()))
-    clk = tot / ((t[:, 13] - t[:, 14]) / 100.0) / 1e3
+    clk = tot / ((t[:, 19] - t[:, 20]) / 100.0) / 1e3
     print('shader clock during the loop (s_memtime cycles / s_memrealtime): mean %.3f GHz (min %.3f, max %.3f)' % (clk.mean(), clk.min(), clk.max()))
     # workgroups of one XCD take consecutive ranges (16 per XCD and net at 256 CUs): is the spread systematic per XCD?
-    for g in sorted(set(int(r[11]) // 16 for r in t)):
-        m = np.array([int(r[11]) // 16 == g for r in t])
+    for g in sorted(set(int(r[17]) // 16 for r in t)):
+        m = np.array([int(r[17]) // 16 == g for r in t])
         print('  ranges %3d..%3d (one XCD): waves finish at %.1f .. %.1f us, mean loop %.0f cycles' % (16 * g, 16 * g + 15, en[m].min(), en[m].max(), tot[m].mean()))
     per_wg = {}
     for r in t:
-        per_wg.setdefault((int(r[10]), int(r[11])), []).append(r[0])
+        per_wg.setdefault((int(r[16]), int(r[17])), []).append(r[0])
     wg_tot = np.array([max(v) for v in per_wg.values()])
     print('workgroups: %d; slowest wave per workgroup: mean %.0f, min %.0f, max %.0f cycles (spread %.1f %%)'
           % (len(wg_tot), wg_tot.mean(), wg_tot.min(), wg_tot.max(), 100 * (wg_tot.max() - wg_tot.min()) / wg_tot.mean()))
@@ -81,7 +86,7 @@ def xcd_series(reps=8):
     x = torch.randn((1, rows, 1), generator=g).to(dev)
     frames = torch.rand((1, rows // 80 + 1, 80), generator=g).to(dev)
     cond = engine.RepeatedCondition(frames, 80, 40, rows)
-    trace = torch.zeros((2 * 256 * 8, 16), dtype=torch.int64, device=dev)
+    trace = torch.zeros((2 * 256 * 8, 24), dtype=torch.int64, device=dev)
     os.environ['PWV_PTRACE_PTR'] = str(trace.data_ptr())
     engine.PERSIST = True
     for _ in range(20):
@@ -96,9 +101,9 @@ def xcd_series(reps=8):
         torch.cuda.synchronize()
         t = trace.cpu().numpy().astype(np.float64)
         t = t[t[:, 5] > 0]
-        t0 = t[:, 14].min()
-        en = (t[:, 13] - t0) / 100.0
-        fin = [en[(t[:, 11] // 16) == x_].max() for x_ in range(8)]
+        t0 = t[:, 20].min()
+        en = (t[:, 19] - t0) / 100.0
+        fin = [en[(t[:, 17] // 16) == x_].max() for x_ in range(8)]
         print('launch %d: last finish per XCD (us): %s  | spread %.1f us' % (k, ' '.join('%6.1f' % v for v in fin), max(fin) - min(fin)))
 
 
