@@ -81,7 +81,8 @@ class GraphedVocoder(object):
             raise
 
     def __call__(self, melspec: torch.Tensor, z: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> torch.Tensor:
-        """melspec [N, t_mel, n_mels]; z [N, length, 1] or None (sample Logistic(0,1), models.py:32-33).
+        """melspec [N, t_mel, n_mels] -- copied into the graph's input buffer, or that buffer itself (`graphed.mel`, filled by the caller:
+        no copy); z [N, length, 1] or None (sample Logistic(0,1), models.py:32-33).
         Returns the graph's output buffer [N, length, 1]: valid until the next call (clone it to keep it).  Enqueue-only, like
         IAFVocoder.__call__(verify=False): call verify() before reading the result."""
         engine.note_forward()
@@ -89,7 +90,8 @@ class GraphedVocoder(object):
             self._capture()      # weights changed (the captured launches point at stale packs) or the engine switched launch paths
         if tuple(melspec.shape) != tuple(self.mel.shape):
             raise ValueError('melspec must be %s (fixed at capture), got %s' % (tuple(self.mel.shape), tuple(melspec.shape)))
-        self.mel.copy_(melspec, non_blocking=True)
+        if melspec is not self.mel:      # (a caller that writes its mel straight into the graph's input buffer `self.mel` passes that: no copy)
+            self.mel.copy_(melspec, non_blocking=True)
         if z is None:
             self.model.sample_noise(self.z.shape[0], self.device, out=self.z, seed=seed)
         else:
