@@ -97,6 +97,7 @@ class GraphedVocoder(object):
         else:
             if tuple(z.shape) != tuple(self.z.shape):
                 raise ValueError('z must be %s, got %s' % (tuple(self.z.shape), tuple(z.shape)))
-            self.z.copy_(z, non_blocking=True)
+            if z is not self.z:
+                self.z.copy_(z, non_blocking=True)
         self.graph.replay()
         return self.out
