@@ -14,7 +14,7 @@ dilated layers, 'repeat' conditioning) on one batch of synthetic input: mel alre
 mels, hop 80) per GPU; utterances shard across GPUs with no data-path collective (weak scaling).
 
 The timed loop replays a HIP graph of the forward (pwv_amd/graph.py; --no-graph enqueues every launch from the
-host); each step samples fresh logistic noise with one eager kernel.
+host); the logistic sampler is a node of that graph and draws a fresh counter range on every replay.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      -- the dominant kernel (fused gated-residual layer): algorithmic bytes (512 B per sample, net and
@@ -393,8 +393,8 @@ def main():
 
             if args.no_graph:
                 return eager_step, eager_step, False
-            # the same launches, captured once into a HIP graph (pwv_amd/graph.py); each step = one eager noise-sampling
-            # kernel (fresh logistic noise every step) + the mel copy + one graph replay
+            # the same launches, captured once into a HIP graph (pwv_amd/graph.py); each step = ONE graph replay: the sampler is a
+            # node of the graph (fresh logistic noise every step, pwv_logistic_noise_stream_f32), the mel sits in the graph's input buffer
             from pwv_amd.graph import GraphedVocoder
             try:
                 graphed = GraphedVocoder(model)
@@ -640,7 +640,7 @@ def main():
                 'parallelism': ('time-sharded x%d: every GPU one slice of the SAME %d x %d samples plus %d samples of recomputed look-back (exact, no data-path collective)'
                                 % (n_gpus, utts, job_length, time_shard['halo'])) if time_shard else 'utterance-sharded x%d (no data-path collective)' % n_gpus,
                 'noise': 'logistic, sampled on device inside the step',
-                'launch': 'HIP graph replay of the forward (noise sampled by an eager kernel per step; the mel resident in the graph\'s input buffer)' if graphed else 'host-enqueued launches',
+                'launch': 'HIP graph replay of the forward: ONE graph launch per step (the logistic sampler is a node of the graph and draws a fresh counter range every replay; the mel resident in the graph\'s input buffer)' if graphed else 'host-enqueued launches',
             },
         }
         if dist is not None:

@@ -105,6 +105,11 @@ int pwv_crop_time_f32(const float* in, float* out, int N, int T_in, int C, int T
  *   (seed, element index + offset): reproducible and shardable.
  * ------------------------------------------------------------------------------------- */
 int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, pwv_stream_t stream);
+/* The same sampler for a launch that is CAPTURED into a HIP graph and replayed (arguments passed by value would repeat the counter
+ * range).  state = four uint64 in DEVICE memory: {seed, offset, 0, skip}.  A launch draws z[i] = the sample of counter offset + i and
+ * -- its last block to finish -- advances state[1] by n, so replay k draws what pwv_logistic_noise_f32(seed, offset + k*n) draws;
+ * state[3] != 0: z is left as the caller filled it and nothing advances; state[2] is the launch's own ticket (zero between launches). */
+int pwv_logistic_noise_stream_f32(float* z, int64_t n, uint64_t* state, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Range guard of the split-fp16 arithmetic (PWV_PREC_F16X3).  The reference computes in fp32 (models.py:81-82);

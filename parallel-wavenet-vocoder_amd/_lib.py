@@ -27,7 +27,7 @@ HEAD_IN_GATED, HEAD_IN_SKIPSUM = 0, 1
 # every symbol include/pwv_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = (
     'pwv_last_error', 'pwv_version', 'pwv_device_cus', 'pwv_causal_conv_f32', 'pwv_linear_f32',
-    'pwv_upsample_repeat_f32', 'pwv_crop_time_f32', 'pwv_logistic_noise_f32', 'pwv_iaf_front_f32',
+    'pwv_upsample_repeat_f32', 'pwv_crop_time_f32', 'pwv_logistic_noise_f32', 'pwv_logistic_noise_stream_f32', 'pwv_iaf_front_f32',
     'pwv_layer_packed_floats', 'pwv_pack_layer_f32', 'pwv_proj_column_map', 'pwv_wavenet_layer_f32',
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
@@ -233,6 +233,7 @@ def _declare(lib):
     lib.pwv_wavenet_stack_persist_f32.argtypes = [POINTER(PersistArgs), c_void_p]
     lib.pwv_range_stats_f32.argtypes = [f32p] * 8 + [c_int, f32p, c_void_p]
     lib.pwv_range_flag.argtypes = [POINTER(c_void_p)]
+    lib.pwv_logistic_noise_stream_f32.argtypes = [f32p, c_int64, c_void_p, c_void_p]
     lib.pwv_cond_project_f32.argtypes = [f32p, f32p, c_int, f32p, f32p, f32p, f32p, c_int, c_int, c_int, ctypes.c_float, c_void_p, c_void_p]
     lib.pwv_status_words_alloc.argtypes = [POINTER(c_void_p)]
     lib.pwv_status_words_free.argtypes = [c_void_p]

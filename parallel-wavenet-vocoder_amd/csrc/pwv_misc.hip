@@ -458,11 +458,8 @@ __global__ void crop_time_kernel(const float* __restrict__ in, float* __restrict
 }
 
 // models.py:32-33: Logistic(0,1) sample = log u - log1p(-u); u from a splitmix64 counter hash
-__global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsigned long long seed,
-                                      unsigned long long offset) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long s = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i + offset;
+__device__ __forceinline__ float logistic_of_counter(unsigned long long seed, unsigned long long counter) {
+    unsigned long long s = seed * 0x9E3779B97F4A7C15ull + counter;
     s += 0x9E3779B97F4A7C15ull;
     s = (s ^ (s >> 30)) * 0xBF58476D1CE4E5B9ull;
     s = (s ^ (s >> 27)) * 0x94D049BB133111EBull;
@@ -470,7 +467,33 @@ __global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsign
     // 23 random bits -> u in [2^-24, 1 - 2^-24]: k + 0.5 is exact in fp32 for k < 2^23, so u is never 0 or 1 (with 24 bits
     // 16777215.5 rounds up to 2^24, u = 1 and z = +inf once in 2^24 samples -- found by the split-fp16 range guard)
     const float u = ((float)(unsigned)(s >> 41) + 0.5f) * (1.0f / 8388608.0f);
-    z[i] = logf(u) - log1pf(-u);
+    return logf(u) - log1pf(-u);
+}
+
+__global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsigned long long seed,
+                                      unsigned long long offset) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    z[i] = logistic_of_counter(seed, (unsigned long long)i + offset);
+}
+
+// The same sampler for a CAPTURED launch (a HIP graph replays the same kernel arguments: a counter range passed by value would
+// repeat).  state = {seed, offset, blocks finished, skip} in device memory: every thread reads seed and offset, the LAST block to
+// finish -- by then every block has read them -- moves the offset on by n and clears the ticket, so the next replay draws the next
+// range: the stream of pwv_logistic_noise_f32(seed, offset), (seed, offset + n), ...  skip != 0: z is the caller's, nothing moves.
+__global__ void logistic_noise_stream_kernel(float* __restrict__ z, long long n, unsigned long long* state) {
+    const unsigned long long seed = state[0], offset = state[1];
+    const bool skip = state[3] != 0;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !skip) z[i] = logistic_of_counter(seed, (unsigned long long)i + offset);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long done = __hip_atomic_fetch_add(&state[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned long long)gridDim.x - 1ull) {
+            if (!skip) __hip_atomic_store(&state[1], offset + (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // modules.py:59 (x = z*s + b) fused with the next flow's causal layer (modules.py:179-180):
@@ -707,6 +730,15 @@ int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, 
     if (n == 0) return PWV_OK;
     hipLaunchKernelGGL(logistic_noise_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, z,
                        (long long)n, (unsigned long long)seed, (unsigned long long)offset);
+    PWV_CHECK_HIP(hipGetLastError());
+    return PWV_OK;
+}
+
+int pwv_logistic_noise_stream_f32(float* z, int64_t n, uint64_t* state, pwv_stream_t stream) {
+    PWV_CHECK_ARG(z && state && n >= 0, "pwv_logistic_noise_stream_f32: bad arguments");
+    if (n == 0) return PWV_OK;
+    hipLaunchKernelGGL(logistic_noise_stream_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, z, (long long)n,
+                       (unsigned long long*)state);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

@@ -407,6 +407,15 @@ def logistic_noise_op(shape: Sequence[int], device, seed: int, offset: int = 0, 
     return z
 
 
+def logistic_noise_stream_op(z: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+    """The sampler in its capturable form (pwv_logistic_noise_stream_f32): `state` = int64[4] on the device, {seed, offset, 0, skip};
+    every launch -- every replay of a captured one -- draws the next z.numel() counters of the stream and moves the offset on."""
+    if state.dtype != torch.int64 or state.numel() != 4 or not state.is_cuda or not z.is_contiguous() or z.dtype != torch.float32:
+        raise ValueError('state must be int64[4] on the GPU, z a contiguous float32 tensor')
+    check(_lib.lib().pwv_logistic_noise_stream_f32(_ptr(z), z.numel(), state.data_ptr(), _stream()), 'pwv_logistic_noise_stream_f32')
+    return z
+
+
 def logistic_noise_window(n: int, total_length: int, first_sample: int, window: int, device, seed: int, first_item: int = 0) -> torch.Tensor:
     """[n, window, 1] Logistic(0,1) noise for the samples [first_sample, first_sample + window) of the utterances
     first_item .. first_item + n - 1 of ONE counter-based stream in which utterance i, sample t is counter

@@ -38,6 +38,10 @@ class GraphedVocoder(object):
         n, length = int(model.batch_size), int(model.length)
         self.mel = torch.zeros((n, model.t_mel, int(hp.signal.n_mels)), dtype=torch.float32, device=self.device)
         self.z = torch.zeros((n, length, 1), dtype=torch.float32, device=self.device)
+        # the sampler is part of the graph: {seed, offset, ticket, skip} in device memory, advanced by the captured kernel itself
+        # (pwv_logistic_noise_stream_f32), so a forward on sampled noise is ONE graph launch and nothing else
+        self.noise_state = torch.zeros((4,), dtype=torch.int64, device=self.device)
+        self._noise_mirror = (0, 0, 0)          # (seed, offset, skip) the device state holds
         self._warmup = warmup
         self._capture()
 
@@ -59,6 +63,7 @@ class GraphedVocoder(object):
         # thread_local: only this thread's calls are policed during capture (an RCCL watchdog thread of a multi-rank
         # job may touch the runtime meanwhile); everything captured here is enqueued from this thread
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
+            engine.logistic_noise_stream_op(self.z, self.noise_state)
             self.out = self.model(None, self.mel, is_training=False, z=self.z)
         self._version = self.store.version
         self._mode = self._launch_mode()
@@ -93,11 +98,24 @@ class GraphedVocoder(object):
         if melspec is not self.mel:      # (a caller that writes its mel straight into the graph's input buffer `self.mel` passes that: no copy)
             self.mel.copy_(melspec, non_blocking=True)
         if z is None:
-            self.model.sample_noise(self.z.shape[0], self.device, out=self.z, seed=seed)
+            # the captured sampler draws the model's next counter range (the stream IAFVocoder.sample_noise draws eagerly); the device
+            # state is written from the host only when it is not what the previous replay left there (first call, another seed,
+            # an eager draw in between, a call with explicit z before)
+            want = (self.model._seed(seed), self.model.noise_offset, 0)
+            self._set_noise_state(want)
+            numel = self.z.numel()
+            self.model.noise_offset += numel
+            self._noise_mirror = (want[0], want[1] + numel, 0)
         else:
             if tuple(z.shape) != tuple(self.z.shape):
                 raise ValueError('z must be %s, got %s' % (tuple(self.z.shape), tuple(z.shape)))
+            self._set_noise_state((self._noise_mirror[0], self._noise_mirror[1], 1))      # skip: z is the caller's
             if z is not self.z:
                 self.z.copy_(z, non_blocking=True)
         self.graph.replay()
         return self.out
+
+    def _set_noise_state(self, want):
+        if want != self._noise_mirror:
+            self.noise_state.copy_(torch.tensor([want[0], want[1], 0, want[2]], dtype=torch.int64), non_blocking=False)
+            self._noise_mirror = want

@@ -470,6 +470,27 @@ def test_one_launch_prologue_is_bit_identical_and_guards_the_range(gpu):
                 assert torch.equal(frames, want_f) and torch.equal(P, want_p), (m, nout)
 
 
+def test_capturable_noise_sampler_draws_the_same_stream(gpu):
+    """pwv_logistic_noise_stream_f32 (the sampler as a node of a HIP graph: {seed, offset, ticket, skip} in device memory, the last block
+    of a launch moves the offset on) against pwv_logistic_noise_f32 with the offsets passed by value: launch k draws the range
+    [offset + k n, offset + (k + 1) n) of the same stream, for sizes that are and are not multiples of the block; skip leaves z and the
+    state alone; the ticket is zero between launches."""
+    import torch
+    from pwv_amd import engine
+    for n_el, seed, off in ((16000, 5, 0), (1000 * 3 + 7, (1 << 55) + 12345, 999983), (1, 9, 3)):
+        state = torch.tensor([seed, off, 0, 0], dtype=torch.int64, device=gpu)
+        z = torch.empty((1, n_el, 1), dtype=torch.float32, device=gpu)
+        for k in range(3):
+            engine.logistic_noise_stream_op(z, state)
+            want = engine.logistic_noise_op((1, n_el, 1), gpu, seed=seed, offset=off + k * n_el)
+            assert torch.equal(z, want)
+            assert state.tolist() == [seed, off + (k + 1) * n_el, 0, 0]
+        state[3] = 1
+        keep = z.clone()
+        engine.logistic_noise_stream_op(z, state)
+        assert torch.equal(z, keep) and state.tolist() == [seed, off + 3 * n_el, 0, 1]
+
+
 def test_plain_c_client_runs(gpu, tmp_path):
     """The C99 client (examples/c_abi_smoke.c) drives pwv_causal_conv_f32 and the tile32 converters with raw
     hipMalloc'd pointers and checks them against loops written in C."""

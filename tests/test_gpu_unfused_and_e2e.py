@@ -294,9 +294,24 @@ def test_graphed_vocoder_matches_eager_bitwise(gpu):
     assert torch.equal(graphed(mel, z=z), want)
     mel2, z2 = mel * 0.5, z.flip(1).contiguous()
     assert torch.equal(graphed(mel2, z=z2).clone(), model(None, mel2, is_training=False, z=z2))
-    a = graphed(mel).clone()          # sampled noise: a fresh counter range per call
+    # sampled noise: the sampler is a node of the graph (pwv_logistic_noise_stream_f32: its counter range lives in device memory and
+    # the captured kernel moves it on), so a forward is ONE graph launch -- and every replay draws the model's next counter range,
+    # exactly what IAFVocoder.sample_noise draws eagerly
+    from pwv_amd import engine
+    model.noise_seed, off, numel = 1234, model.noise_offset, n * length
+    a = graphed(mel).clone()
     b = graphed(mel).clone()
-    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    assert torch.isfinite(a).all() and not torch.equal(a, b) and model.noise_offset == off + 2 * numel
+    za = engine.logistic_noise_op((n, length, 1), gpu, seed=1234, offset=off)
+    zb = engine.logistic_noise_op((n, length, 1), gpu, seed=1234, offset=off + numel)
+    assert torch.equal(a, model(None, mel, is_training=False, z=za)) and torch.equal(b, model(None, mel, is_training=False, z=zb))
+    eager = model(None, mel, is_training=False).clone()                      # an eager draw in between takes the next range ...
+    zc = engine.logistic_noise_op((n, length, 1), gpu, seed=1234, offset=off + 2 * numel)
+    assert torch.equal(eager, model(None, mel, is_training=False, z=zc))
+    c = graphed(mel, seed=77).clone()                                        # ... and the graph goes on behind it, here with another seed
+    zd = engine.logistic_noise_op((n, length, 1), gpu, seed=77, offset=off + 3 * numel)
+    assert torch.equal(c, model(None, mel, is_training=False, z=zd))
+    assert torch.equal(graphed(mel, z=z), want)                              # explicit z again: the sampler node leaves it alone
     name = 'iaf_vocoder/iaf0/scalar/postprocessing/postprocess2_bias'
     store.assign(name, (store.vars[name] + 0.25).cpu().numpy())
     got = graphed(mel, z=z).clone()
