@@ -9,8 +9,9 @@ bit-identical results, 2 % faster at 160000 samples, 12 % at 16000 samples, 37 %
 
 No tracing and no compiler: the graph is exactly the launches `IAFVocoder.__call__` enqueues, with the buffers torch's
 graph-private pool handed out during capture.  Shapes are fixed at capture (batch, length); the mel and the noise
-are copied into static input tensors before each replay, and the noise is sampled by an eager kernel launch (a
-captured sampler would replay the same counter range).
+are copied into static input tensors before each replay (or written there by the caller: `graphed.mel`), and the noise is
+sampled by a node of the graph whose counter range lives in device memory (pwv_logistic_noise_stream_f32: a sampler with its
+range passed by value would replay the same noise).
 """
 from __future__ import annotations
 
