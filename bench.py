@@ -493,6 +493,26 @@ def main():
     # `value` (whose timed loop is forward-only: every rank on its own resident mel)
     sharded, job = None, None
     JOB_CALLS = 5
+    job_errors = []          # a forward that fails on ONE rank must not strand the others in the gather: zeros out, collectives stay paired,
+                             # and the failure bit below stops every rank (generate._generate_over_ranks does the same)
+
+    def guarded_fwd(f, shape_of):
+        def g(*a):
+            try:
+                return f(*a)
+            except Exception as e:      # noqa: BLE001
+                job_errors.append(e)
+                return torch.zeros(shape_of(*a), dtype=torch.float32, device=a[0].device)
+        return g
+
+    def raise_if_any_rank_failed():
+        bad = 1 if job_errors else 0
+        if dist is not None:
+            t = torch.tensor([bad], dtype=torch.int32, device='cpu' if dryrun else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bad = int(t.item())
+        if bad:
+            raise job_errors[0] if job_errors else RuntimeError('bench.py: the sharded forward failed on another rank')
 
     def timed_job(call):
         call()                                   # (untimed: model objects for the shard shapes, plans, RCCL channels)
@@ -525,7 +545,9 @@ def main():
                     nets_by_window[win] = model0 if win == length else IAFVocoder(batch_size=m.shape[0], length=win, store=store, precision=args.precision)
                 zw = engine.logistic_noise_window(m.shape[0], job_length, t0, win, dev, 4242)
                 return nets_by_window[win](None, m.to(dev), is_training=False, z=zw, verify=True).to(coll_dev)      # (a verified call: rerun inside if a sticky word is raised)
+        fwd = guarded_fwd(fwd, lambda m, zz, t0: (m.shape[0], (m.shape[1] - 1) * hop, 1))
         wav, job_s, job_times = timed_job(lambda: generate_time_sharded_ranks(fwd, full_mel, n_mels, job_length, hop, time_shard['halo'], coll_dev))
+        raise_if_any_rank_failed()
         job_samples = utts * job_length
         if rank == 0:
             assert tuple(wav.shape) == (utts, job_length, 1) and bool(torch.isfinite(wav).all())
@@ -548,7 +570,9 @@ def main():
                 if nb not in nets_by_batch:
                     nets_by_batch[nb] = model0 if nb == utts else IAFVocoder(batch_size=nb, length=length, store=store, precision=args.precision)
                 return nets_by_batch[nb](None, m.to(dev), is_training=False, z=zz, verify=True).to(coll_dev)      # (a verified call)
+        fwd = guarded_fwd(fwd, lambda m, zz: (m.shape[0], length, 1))
         wav, job_s, job_times = timed_job(lambda: generate_sharded(fwd, full_mel, (t_mel, n_mels), length, coll_dev))
+        raise_if_any_rank_failed()
         job_samples = total * length
         if rank == 0:
             assert tuple(wav.shape) == (total, length, 1) and bool(torch.isfinite(wav).all())
