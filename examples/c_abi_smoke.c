@@ -6,7 +6,9 @@
  * (tests/test_abi.py compiles it on every run, tests/test_gpu_parity.py runs it on the GPU)
  *
  * Runs modules.causal_conv (modules.py:11-43) and the tile32 round trip on the GPU and checks them against loops
- * written here.  Exit code 0 = match. */
+ * written here; then the round-5 entry points a C caller needs for a serving loop: its OWN pair of sticky words
+ * (pwv_status_words_alloc) with the range guard reporting into it, and the capturable logistic sampler
+ * (pwv_logistic_noise_stream_f32) against the by-value one (models.py:32-33).  Exit code 0 = match. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
@@ -63,5 +65,41 @@ int main(void) {
     /* error behaviour: bad arguments come back as a negative code plus a message, nothing is launched */
     const int rc = pwv_causal_conv_f32(NULL, df, dy, N, T, CIN, COUT, W, D, NULL);
     printf("causal_conv max |err| = %.3g, tile32 round trip mismatches = %d, NULL input -> %d (\"%s\")\n", err, bad, rc, pwv_last_error());
-    return (err <= 1e-5 && bad == 0 && rc == PWV_EINVAL) ? 0 : 1;
+
+    /* this caller's own sticky words: words[0] would go into pwv_persist_args.status, words + 1 is its range flag */
+    int* words = NULL;
+    CHECK_PWV(pwv_status_words_alloc(&words));
+    CHECK_PWV(pwv_range_check_f32(drows, (int64_t)N * T * C, 2.0f, words + 1, NULL));      /* rows are in [0, 1): in range */
+    CHECK_HIP(hipDeviceSynchronize());
+    const int flag_clean = words[1];
+    CHECK_PWV(pwv_range_check_f32(drows, (int64_t)N * T * C, 0.5f, words + 1, NULL));      /* ... and not below 0.5 */
+    CHECK_HIP(hipDeviceSynchronize());
+    const int flag_raised = words[1], give_up_word = words[0];
+    words[1] = 0;
+
+    /* the sampler in its capturable form: state = {seed, offset, ticket, skip} in device memory; launch k draws the counters
+     * [offset + k n, offset + (k + 1) n) of the stream pwv_logistic_noise_f32(seed, .) draws by value */
+    enum { NZ = 1000 };
+    static float za[NZ], zb[NZ];
+    float *dza, *dzb;
+    uint64_t state[4] = {77u, 12345u, 0u, 0u}, *dstate;
+    int noise_bad = 0, kk;
+    CHECK_HIP(hipMalloc((void**)&dza, sizeof za));
+    CHECK_HIP(hipMalloc((void**)&dzb, sizeof zb));
+    CHECK_HIP(hipMalloc((void**)&dstate, sizeof state));
+    CHECK_HIP(hipMemcpy(dstate, state, sizeof state, hipMemcpyHostToDevice));
+    for (kk = 0; kk < 3; ++kk) {
+        CHECK_PWV(pwv_logistic_noise_stream_f32(dza, NZ, dstate, NULL));
+        CHECK_PWV(pwv_logistic_noise_f32(dzb, NZ, 77u, 12345u + (uint64_t)kk * NZ, NULL));
+        CHECK_HIP(hipDeviceSynchronize());
+        CHECK_HIP(hipMemcpy(za, dza, sizeof za, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(zb, dzb, sizeof zb, hipMemcpyDeviceToHost));
+        for (i = 0; i < NZ; ++i) noise_bad += za[i] != zb[i];
+    }
+    CHECK_HIP(hipMemcpy(state, dstate, sizeof state, hipMemcpyDeviceToHost));
+    const int state_ok = state[0] == 77u && state[1] == 12345u + 3u * NZ && state[2] == 0u && state[3] == 0u;
+    printf("own status words: range flag %d -> %d (give-up word %d); capturable sampler: %d mismatches over 3 launches, state %s\n",
+           flag_clean, flag_raised, give_up_word, noise_bad, state_ok ? "advanced by 3 n" : "WRONG");
+    CHECK_PWV(pwv_status_words_free(words));
+    return (err <= 1e-5 && bad == 0 && rc == PWV_EINVAL && flag_clean == 0 && flag_raised == 1 && give_up_word == 0 && noise_bad == 0 && state_ok) ? 0 : 1;
 }
