@@ -161,25 +161,57 @@ class PersistArgs(Structure):
     ]
 
 
+# per-source extra flags (none in the product; tools/probes/regw/README.md: the register-stationary probe kernel needs
+# `-mllvm -amdgpu-mfma-vgpr-form=1`, which is why the sources are compiled one by one)
+EXTRA_FLAGS = {}
+# extra sources for probe builds: PWV_EXTRA_SRC="path[:flag,flag...] ..."
+for _e in os.environ.get('PWV_EXTRA_SRC', '').split():
+    _src, _, _fl = _e.partition(':')
+    CSRC.append(os.path.abspath(_src))
+    EXTRA_FLAGS[os.path.basename(_src)] = [f for f in _fl.split(',') if f]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into the in-tree shared library."""
-    srcs = CSRC + [os.path.join(_PKG_DIR, 'csrc', h) for h in ('pwv_common.h', 'pwv_layer_common.h', 'pwv_f16x3.h')] + [os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
+    """Compile the HIP sources for gfx950 into the in-tree shared library (one object per source, compiled in parallel and
+    reused while the source and the headers are older than it)."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(_PKG_DIR, 'csrc', h) for h in ('pwv_common.h', 'pwv_layer_common.h', 'pwv_f16x3.h')] + [os.path.join(_REPO_ROOT, 'include', 'pwv_hip.h')]
     if os.environ.get('PWV_LIB'):
         return LIB_PATH            # an explicitly chosen library is never rebuilt
     if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in CSRC + hdrs):
             return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    # two gfx950 code objects, one per XNACK mode of the device (the loader picks the match): code built for a known mode
-    # instead of 'either' is 0.5 % faster on the bench step (the default mode of an MI355X is xnack-)
-    cmd = [hipcc, '--offload-arch=gfx950:xnack-', '--offload-arch=gfx950:xnack+', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-I' + os.path.join(_REPO_ROOT, 'include'), '-I' + os.path.join(_PKG_DIR, 'csrc'),
-           '-o', LIB_PATH] + CSRC
+    objdir = os.path.join(_PKG_DIR, 'csrc', '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    # ONE gfx950 code object for the XNACK mode an MI355X runs in by default (xnack-): code built for a known mode instead of
+    # 'either' is 0.5 % faster on the bench step; xnack+ objects (XNACK-on runs) are not available on the GPU pool
+    base = [hipcc, '--offload-arch=gfx950:xnack-', '-O3', '-std=c++17', '-fPIC',
+            '-I' + os.path.join(_REPO_ROOT, 'include'), '-I' + os.path.join(_PKG_DIR, 'csrc')]
+    extra = os.environ.get('PWV_CXXFLAGS', '').split()
+    hdr_time = max(os.path.getmtime(h) for h in hdrs + [os.path.abspath(__file__)])
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ('.' + '_'.join(extra).replace('/', '_') if extra else '') + '.o')
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            return obj, None
+        cmd = base + EXTRA_FLAGS.get(os.path.basename(src), []) + extra + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return obj, (res.stdout if res.returncode != 0 else None)
+
+    with ThreadPoolExecutor(max_workers=min(len(CSRC), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, CSRC))
+    for obj, err in results:
+        if err is not None:
+            raise PwvError('hipcc failed:\n' + err)
+    cmd = [hipcc, '--offload-arch=gfx950:xnack-', '-shared', '-fPIC', '-o', LIB_PATH] + [o for o, _ in results]
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise PwvError('hipcc failed:\n' + res.stdout)
+        raise PwvError('hipcc (link) failed:\n' + res.stdout)
     return LIB_PATH
 
 

@@ -54,7 +54,7 @@ FUSE_FIRST = True
 FUSE_HEAD = True
 # the net's last layer + head -- and the flow's affine -- run INSIDE the persistent launch (pwv_persist_args.tail_*, split-fp16 path):
 # a flow is one launch instead of three.  Tests switch it off to check the fused form bit for bit against the separate launches.
-FUSE_TAIL = os.environ.get('PWV_FUSE_TAIL', '1') != '0'      # (PWV_FUSE_TAIL=0: A/B runs of tools/r05_run2.sh)
+FUSE_TAIL = os.environ.get('PWV_FUSE_TAIL', '1') != '0'      # (PWV_FUSE_TAIL=0: A/B runs of tools/runs/r05_run2.sh)
 HOIST_P = True               # one projection GEMM per forward (project_all); False: every net projects for itself (cross-check in tests)
 # PWV_FOLD_FIRST=0: layer 0 runs its filter|gate GEMM on the rebuilt causal-layer rows (eight MFMA k-steps) instead of on the
 # four scalars they are a function of (one k-step); default: folded.  The only knob that changes bits (measured in HISTORY.md section 4, K2).

@@ -16,7 +16,7 @@ mkdir -p "$root/tools/abl_so"
 for v in "$@"; do
     name=${v%%:*}; defs=${v#*:}; [ "$defs" = "$v" ] && defs=$name
     flags=""; for d in $defs; do flags="$flags -DPWV_$d"; done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950:xnack- --offload-arch=gfx950:xnack+ -O3 -std=c++17 -shared -fPIC $flags -I"$root/include" -I"$tmp/csrc" \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950:xnack- -O3 -std=c++17 -shared -fPIC $flags -I"$root/include" -I"$tmp/csrc" \
         -o "$root/tools/abl_so/libpwv_$name.so" "$tmp"/csrc/*.hip
     echo "built tools/abl_so/libpwv_$name.so ($flags)"
 done
