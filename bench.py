@@ -118,14 +118,19 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process'):
+def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process', per=4):
     """Oracle port (torch-CPU fp32 restatement of modules.py:11-259 / models.py:23-136) timed on the host cores on a bounded
     sample of the same model (k = 1 and k = all physical cores; generate.py:47-50 is the reference's own
     CPU / GPU switch).  Evaluated flow by flow in time chunks of `chunk` samples with each flow's look-back recomputed
     (oracle/torch_cpu.py ChunkedForward: the same function; a chunk's working set stays in cache instead of streaming 41 MB
     tensors through DRAM) and with one chunk per core at a time (k workers x single-threaded ops) instead of every small conv
-    split over all cores -- the form in which this math scales on a many-core host.  Sweep {1, 2, 4, 8, 16, 32, physical cores}
-    on 2k chunks each (constant time per point), then the best k on a sample sized to `target_s` seconds."""
+    split over all cores -- the form in which this math scales on a many-core host.
+
+    Every point of the sweep {1, 2, 4, 8, 16, 32, physical cores} is measured the same way (beyond 16
+    workers the sweep used to time ONE chunk per worker, i.e. the pool's start-up): the pool is started and WARMED (one untimed
+    chunk per worker: processes forked, op primitives created, pages touched), then a forward over `per` = 4 chunks per worker is
+    timed.  The reported value is the best k measured AGAIN on that very sample, repeated until `target_s` seconds are filled --
+    so `value_best` and its own sweep point are the same experiment."""
     from oracle import iaf_oracle as O
     from oracle.torch_cpu import ChunkedForward
     w = O.init_weights(case_cfg, seed=2)
@@ -133,41 +138,49 @@ def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process'):
     chunk = max(hop, chunk // hop * hop)
     logical, phys = os.cpu_count() or 1, physical_cores()
     sweep = sorted({k for k in (1, 2, 4, 8, 16, 32, phys) if k <= logical})
-    rates, fwd = {}, {}
-    for k in sweep:
-        f = fwd[k] = ChunkedForward(w, case_cfg, chunk, k, mode)
-        per = 2 if k <= 16 else 1                                       # (chunks per worker: keeps every point of the sweep to a second or two)
-        mel, z = O.synthetic_inputs(1, chunk * per * k, case_cfg)
-        t0 = time.perf_counter()
-        f(mel, z)
-        rates[k] = chunk * per * k / (time.perf_counter() - t0)
-        if k != 1:
+
+    def point(k, seconds=0.0, per_k=per):
+        f = ChunkedForward(w, case_cfg, chunk, k, mode)
+        try:
+            f(*O.synthetic_inputs(1, chunk * k, case_cfg))                      # warm: one chunk per worker, untimed
+            mel, z = O.synthetic_inputs(1, chunk * per_k * k, case_cfg)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                y = f(mel, z)
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    break
+            assert np.isfinite(y).all()
+            return chunk * per_k * k * n / dt, chunk * per_k * k * n, dt
+        finally:
             f.close()
+
+    rates, pers, prev = {}, {}, None
+    for k in sweep:
+        # `per` chunks per worker -- fewer only where the point would run beyond ~20 s at the rate of the point before it (the
+        # physical-core point of a 128-core host past the memory-bound knee: 2 M samples at a third of the best rate)
+        pers[k] = per if prev is None else int(max(1, min(per, 20.0 * prev // (k * chunk))))
+        rates[k] = prev = point(k, per_k=pers[k])[0]
     best = max(rates, key=lambda k: rates[k])
-    fwd[1].close()
-    n_chunks = int(max(best, min(160000 // chunk, rates[best] * target_s // chunk)))
-    n_chunks = max(best, n_chunks // best * best)                  # whole rounds of `best` chunks
-    length = n_chunks * chunk
-    f = ChunkedForward(w, case_cfg, chunk, best, mode)
-    mel, z = O.synthetic_inputs(1, length, case_cfg)
-    t0 = time.perf_counter()
-    y = f(mel, z)
-    dt = time.perf_counter() - t0
-    f.close()
-    assert np.isfinite(y).all()
+    first_pass = rates[best]
+    value, length, dt = point(best, target_s, pers[best])      # the best k again, on the same sample, until target_s seconds are filled ...
+    rates[best] = value                                        # ... and THAT is its point of the sweep (the first pass is kept beside it)
     cpu_model = 'unknown CPU'
     try:
         with open('/proc/cpuinfo') as fh:
             cpu_model = next(l.split(':', 1)[1].strip() for l in fh if l.startswith('model name'))
     except Exception:
         pass
-    return {'value': length / dt, 'unit': 'samples/s', 'cores': best, 'kind': 'port',
-            'value_1thread': rates[1], 'value_best': length / dt, 'threads_swept': {str(k): round(v, 1) for k, v in rates.items()},
-            'physical_cores': phys, 'logical_cpus': logical, 'cpu': cpu_model, 'chunk_samples': chunk, 'workers': mode,
-            'sample': 'same model, 1 utterance x %d samples (%.1f s wall on %d cores), torch-CPU fp32 restatement of the reference math '
-                      '(oracle/torch_cpu.py, conditioning per sample as written) evaluated in %d-sample time chunks with the flow\'s look-back '
-                      'recomputed, one chunk per core at a time (%s pool); sweep on 2k chunks (k chunks beyond 16 workers) for k in %s, best = %d; value_1thread is the k = 1 point'
-                      % (length, dt, best, chunk, mode, sorted(rates), best)}
+    return {'value': value, 'unit': 'samples/s', 'cores': best, 'kind': 'port',
+            'value_1thread': rates[1], 'value_best': value, 'value_best_first_pass': first_pass, 'value_physical_cores': rates.get(phys),
+            'threads_swept': {str(k): round(v, 1) for k, v in rates.items()}, 'chunks_per_worker_by_k': {str(k): v for k, v in pers.items()},
+            'physical_cores': phys, 'logical_cpus': logical, 'cpu': cpu_model, 'chunk_samples': chunk, 'chunks_per_worker': per, 'workers': mode,
+            'sample': 'same model, 1 utterance x %d samples per forward (%d chunks of %d per worker), %d samples in %.1f s wall on %d workers; torch-CPU fp32 '
+                      'restatement of the reference math (oracle/torch_cpu.py, conditioning per sample as written) evaluated in time chunks with the '
+                      'flow\'s look-back recomputed, one chunk per core at a time (%s pool, started and warmed before the clock); sweep over k in %s '
+                      'on the same kind of sample (%d chunks per worker), best = %d; value_1thread is the k = 1 point'
+                      % (chunk * per * best, per, chunk, length, dt, best, mode, sorted(rates), per, best)}
 
 
 def cpu_baseline(case, case_cfg, target_s):
@@ -790,6 +803,19 @@ def main():
                 'value': v32, 'unit': 'samples/s', 'ms_per_step': e32 / n32 * 1e3, 'steps': n32,
                 'alg_TFLOPs': mf * v32 / n_gpus / 1e12, 'mfma_frac': mf * v32 / n_gpus / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 'launch': 'HIP graph replay' if g32 else 'host-enqueued launches'}
+        if not control and args.precision == 'f16x3':
+            # how far this workload stays from the range guard of the split-fp16 arithmetic (untimed, one eager forward with the
+            # run-time maxima read back): limit / observed per operand class, `range_margin` = the smallest (engine.range_report)
+            try:
+                zr = engine.logistic_noise_op((utts, length, 1), dev, seed=4242)
+                rr = engine.range_report(lambda: model0(None, mel, is_training=False, z=zr, verify=False))
+                model0.verify()
+                result['range_guard'] = {'range_margin': rr['range_margin'],
+                                         'classes': {k: {kk: float('%.6g' % vv) for kk, vv in c.items()} for k, c in rr['classes'].items()},
+                                         'note': 'limit / observed (or bounded) maximum per fp16 operand class of this workload; below 1 the forward '
+                                                 'would be rerun in exact fp32 (f32_exact is that path)'}
+            except Exception as e:
+                sys.stderr.write('range report failed (%s: %s)\n' % (type(e).__name__, e))
         if n_gpus == 1 and not args.no_cpu_baseline and not control:
             from oracle.iaf_oracle import ModelConfig          # the oracle is only ever the CPU leg, never the timed path
             result['cpu_baseline'] = cpu_baseline(args.case, ModelConfig.from_hparam(hp), args.cpu_seconds)

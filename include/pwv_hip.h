@@ -50,6 +50,10 @@ extern "C" {
 typedef void* pwv_stream_t;
 
 const char* pwv_last_error(void);
+/* PWV_HIP_VERSION of the library that was loaded: major * 100 + minor.  A change of the major number changes the layout of an
+ * argument struct: 3xx = pwv_persist_args begins with `struct_size`.  A client compiled against this header checks
+ * pwv_version() / 100 == PWV_HIP_VERSION / 100 once after loading the library. */
+#define PWV_HIP_VERSION 300
 int pwv_version(void);
 /* number of compute units of the current device (grid sizing); <0 on error */
 int pwv_device_cus(void);
@@ -108,7 +112,9 @@ int pwv_logistic_noise_f32(float* z, int64_t n, uint64_t seed, uint64_t offset, 
 /* The same sampler for a launch that is CAPTURED into a HIP graph and replayed (arguments passed by value would repeat the counter
  * range).  state = four uint64 in DEVICE memory: {seed, offset, 0, skip}.  A launch draws z[i] = the sample of counter offset + i and
  * -- its last block to finish -- advances state[1] by n, so replay k draws what pwv_logistic_noise_f32(seed, offset + k*n) draws;
- * state[3] != 0: z is left as the caller filled it and nothing advances; state[2] is the launch's own ticket (zero between launches). */
+ * state[3] != 0: z is left as the caller filled it and nothing advances; state[2] is the launch's own ticket (zero between launches).
+ * ONE launch per `state` in flight at a time: two launches that share a state must be ordered (one stream, or one graph replayed on
+ * one stream) -- overlapping ones would share the ticket. */
 int pwv_logistic_noise_stream_f32(float* z, int64_t n, uint64_t* state, pwv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -401,7 +407,7 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
  * csrc/pwv_stack_persist.hip has the protocol.  The call enqueues (unless `workspace_clean`) a kernel that zeroes the control words and one kernel
  * (grid <= one workgroup per CU; max_workgroups > 0 limits it further, e.g. to share the chip with another stream).
  *   pwv_persist_workspace_bytes   size of `workspace` (device memory, 256-byte aligned, contents don't care) for the shape in
- *                                 `args` (G, N, T, n_layers, dilations, max_workgroups, min_units_per_workgroup are read);
+ *                                 `args` (G, N, T, n_layers, dilations, max_workgroups, min_units_per_workgroup, tail_q, tail_dilation are read);
  *                                 0 = this shape cannot run as a persistent launch (pwv_last_error says why): use the
  *                                 per-layer launches
  *   pwv_persist_status(&p)        process-wide sticky int32 in pinned host memory: 0, or != 0 once a launch gave up
@@ -410,6 +416,11 @@ int pwv_wav_to_mel_db_f32(const float* wav, const float* window, const float* me
  *                                 uses the per-layer path.
  * ------------------------------------------------------------------------------------- */
 typedef struct pwv_persist_args {
+    size_t struct_size;                           /* = sizeof(pwv_persist_args) as the CALLER was compiled.  The library reads that many bytes and
+                                                   * treats every field behind them as zero / NULL, so fields appended in later minor versions
+                                                   * (the status word, the tail, the affine) cannot be read out of a shorter caller's memory;
+                                                   * 0 or less than the fields up to `min_units_per_workgroup` is PWV_EINVAL.  Zero-initialise
+                                                   * the struct (`pwv_persist_args a = {0}; a.struct_size = sizeof a;`) before filling it in. */
     int G;
     int n_layers;                                 /* 2..32 layers in this launch */
     const int* dilations;                         /* HOST array [n_layers] */

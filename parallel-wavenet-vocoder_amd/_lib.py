@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so') 
 CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip',
                                                     'pwv_stack_persist.hip', 'pwv_norm.hip', 'pwv_audio.hip')]
 
+HEADER_VERSION = 300          # PWV_HIP_VERSION of include/pwv_hip.h these ctypes mirrors were written against
 FIRST_FOLD_FLOATS = 2048      # PWV_FIRST_FOLD_FLOATS
 PWV_MAX_NETS = 2
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
@@ -127,6 +128,7 @@ class StackArgs(Structure):
 
 class PersistArgs(Structure):
     _fields_ = [
+        ('struct_size', c_size_t),      # set by __init__
         ('G', c_int),
         ('n_layers', c_int),
         ('dilations', POINTER(c_int)),
@@ -159,6 +161,11 @@ class PersistArgs(Structure):
         ('affine_x', c_void_p),
         ('affine_out', c_void_p),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(PersistArgs)
+
 
 
 # per-source extra flags (none in the product; tools/probes/regw/README.md: the register-stationary probe kernel needs
@@ -290,9 +297,14 @@ def lib():
         if os.path.exists(hip_rt):
             ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
         try:
-            _lib = _declare(ctypes.CDLL(LIB_PATH))
+            loaded = _declare(ctypes.CDLL(LIB_PATH))
         except OSError as e:
             raise PwvError('cannot load %s: %s' % (LIB_PATH, e))
+        # a major version step changes an argument struct's layout (include/pwv_hip.h): never call across one
+        if loaded.pwv_version() // 100 != HEADER_VERSION // 100:
+            raise PwvError('%s is version %d, this binding was written against %d: rebuild it (`python -c "import __graft_entry__ as g; g.build()"`)'
+                           % (LIB_PATH, loaded.pwv_version(), HEADER_VERSION))
+        _lib = loaded
     return _lib
 
 

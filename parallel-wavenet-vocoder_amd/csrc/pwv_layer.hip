@@ -37,7 +37,34 @@ struct TileRegs {
     bool valid;
 };
 
-template <bool SKIP, bool COND, bool FIRST = false>
+// the skip-sum row [128] of a unit: chunk for (it, q) = channel quad 8*it + 2*q + h
+template <bool SKIP, bool COND>
+__device__ __forceinline__ void load_skip_row(const LayerParams& p, int net, int lane, TileRegs<SKIP, COND>& r, bool skip_load) {
+    if constexpr (SKIP) {
+        const int h = lane >> 5;
+        const int rows = p.N * p.T;
+        const int rc = r.valid ? r.row : rows - 1;
+        if (skip_load) {
+            const float* srow = p.skip[net] + tile_off(rc, h, 128);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r.sk[it * 16 + q * 4 + e] = v[e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) r.sk[i] = 0.f;
+        }
+    }
+}
+
+// SK_NOW = false: the skip-sum row is NOT loaded with the tile (8-wave kernels request it in front of GEMM2 / the gating instead:
+// its 64 registers next to x[t-d], x[t], P and the per-sample condition at the top of the unit were the 27-35 spilled VGPRs of the
+// SKIP + COND variants)
+template <bool SKIP, bool COND, bool FIRST = false, bool SK_NOW = true>
 __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int unit, int lane,
                                           TileRegs<SKIP, COND>& r, bool skip_load) {
     const int h = lane >> 5;
@@ -68,23 +95,7 @@ __device__ __forceinline__ void load_tile(const LayerParams& p, int net, int uni
     if (p.cond_hop > 0) prow = n * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
     load_contig<16>(p.proj[net] + (size_t)prow * p.proj_row_stride + h * 64, r.pj);
     if constexpr (COND) load_tiled<10, kCondC>(p.cond, rc, h, true, r.cd);
-    if constexpr (SKIP) {
-        // skip row [128]: chunk for (it, q) = channel quad 8*it + 2*q + h
-        if (skip_load) {
-            const float* srow = p.skip[net] + tile_off(rc, h, 128);
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r.sk[it * 16 + q * 4 + e] = v[e];
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 64; ++i) r.sk[i] = 0.f;
-        }
-    }
+    if constexpr (SKIP && SK_NOW) load_skip_row<SKIP, COND>(p, net, lane, r, skip_load);
 }
 
 // Work is handed out in 32-row units (one MFMA column tile = one wave's worth of samples).
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
 
     while (unit < u_end) {
         const int next = PREFETCH ? unit + WAVES : 0;
-        if constexpr (!PREFETCH) load_tile<SKIP, COND, FIRST>(p, net, unit, lane, cur, skip_load);
+        if constexpr (!PREFETCH) load_tile<SKIP, COND, FIRST, false>(p, net, unit, lane, cur, skip_load);
         float first_x0 = 0.f, first_x1 = 0.f;      // FIRST: x[t], x[t-1]
         float fold_b0 = 0.f, fold_b1 = 0.f;        // FOLD: the B values of the two k-steps
         (void)first_x0;
@@ -346,6 +357,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
                 if (cur.valid && h == 0) p.head_out[net][(size_t)cur.row * Q + q] = part;
             }
         } else if constexpr (GATED) {
+            if constexpr (SKIP && !PREFETCH) load_skip_row<SKIP, COND>(p, net, lane, cur, skip_load);      // in flight under the gating
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
             if (cur.valid) {
@@ -376,6 +388,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_f32_kernel(const LayerParams
                     }
                 }
             }
+            if constexpr (SKIP && !PREFETCH) load_skip_row<SKIP, COND>(p, net, lane, cur, skip_load);      // in flight under GEMM2
             // k-steps 0..15 use o tile 0 (ready); pair 1 is gated under those MFMAs
             gemm_groups<8, 2, 0, 1>(
                 lds, kA2, lane, acc2, a, [&](int ks) -> float { return o[ks]; },

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
             },
             [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
                 if constexpr (!GATED) first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl);
-                else if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
+                else if constexpr (SKIP) first_frags<4, 2, 0, 1, 4>(AS, lane, nh, nl);
             });
         }
 
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 if (valid && h == 0) p.head_out[net][(size_t)row * Q + q] = part;
             }
         } else if constexpr (GATED) {
-            load_x(next, rxb, rxc);
+            if constexpr (!SKIP) load_x(next, rxb, rxc);      // (SKIP: requested in front of the skip GEMM, see below)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
@@ -402,9 +402,11 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc2[it][q * 4 + e] = xc[it * 16 + q * 4 + e] + bd[e];
                 }
-            // next unit's rows: in flight under GEMM2 + gating + stores (xc is dead from here on)
+            // next unit's rows: in flight under GEMM2 + gating + stores (xc is dead from here on).  With skip accumulation they are
+            // requested behind this layer's stores instead, in front of the skip GEMM (48 MFMAs of cover): their 64 registers on top
+            // of GEMM2's working set were the 19-37 spilled VGPRs of the SKIP variants
             asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
-            load_x(next, rxb, rxc);
+            if constexpr (!SKIP) load_x(next, rxb, rxc);
             __builtin_amdgcn_sched_barrier(0);
             gemm16<4, 2, 0, 1, 2>(
                 A2, lane, acc2, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; },
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                     }
                 },
                 [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
-                    if constexpr (SKIP) first_frags<4, 4, 0, 1, 4>(AS, lane, nh, nl);
+                    if constexpr (SKIP) first_frags<4, 2, 0, 1, 4>(AS, lane, nh, nl);
                 });
             PWV_STAMP(6);
             if (valid) {
@@ -433,33 +435,49 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         }
 
         if constexpr (SKIP) {
-            // ---- skip 64 -> 128, accumulated across layers ------------------------------------------
+            // ---- skip 64 -> 128, accumulated across layers: two passes of two row tiles (64 outputs) each.  One pass over all four
+            // tiles held 64 accumulator + 64 fragment registers (current + next k-step of four tiles) next to the gated operand and the
+            // prefetched rows: 19-37 spilled VGPRs in every SKIP variant.  Same per-accumulator operation order.
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(next, rxb, rxc);      // the next unit's rows: in flight under the skip GEMM (48 MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 accs[4];
             float* srow = p.skip[net] + tile_off(rc, h, 128);
             const bool skip_load = !p.skip_init;
+            const __amdgpu_buffer_rsrc_t skip_rs = units_rsrc(p.skip[net], u_begin, u_end, 32 * 128 * 4);
+            const int soff = units_off(row, h, 128, u_begin);
+            auto skip_init2 = [&](int it0) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kBS + h * 64 + it * 16 + q * 4]);
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (skip_load) v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e] + bs[e];
-                }
-            gemm16<4, 4, 0, 1, 4>(AS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; },
-                                  [&](int s) -> f16x8 { return ol[s]; }, no_extra, [](f16x8(&)[4], f16x8(&)[4]) {});
-            if (valid) {
-                const __amdgpu_buffer_rsrc_t skip_rs = units_rsrc(p.skip[net], u_begin, u_end, 32 * 128 * 4);
-                const int soff = units_off(row, h, 128, u_begin);
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
+                for (int it = it0; it < it0 + 2; ++it)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
-                        store_wt(skip_rs, soff + (8 * it + 2 * q) * 512, v);
+                        const f32x4 bs = *reinterpret_cast<const f32x4*>(&lds[kBS + h * 64 + it * 16 + q * 4]);
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (skip_load) v = *reinterpret_cast<const f32x4*>(srow + (8 * it + 2 * q) * 128);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e] + bs[e];
                     }
-            }
+            };
+            auto skip_store2 = [&](int it0) {
+                if (valid) {
+#pragma unroll
+                    for (int it = it0; it < it0 + 2; ++it)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = {accs[it][q * 4], accs[it][q * 4 + 1], accs[it][q * 4 + 2], accs[it][q * 4 + 3]};
+                            store_wt(skip_rs, soff + (8 * it + 2 * q) * 512, v);
+                        }
+                }
+            };
+            skip_init2(0);
+            gemm16<4, 2, 0, 1, 4>(AS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; }, no_extra,
+                                  [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<4, 2, 2, 1, 4>(AS, lane, nh, nl); });
+            skip_store2(0);
+            __builtin_amdgcn_sched_barrier(0);
+            skip_init2(2);
+            gemm16<4, 2, 2, 1, 4>(AS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; }, no_extra,
+                                  [](f16x8(&)[4], f16x8(&)[4]) {});
+            skip_store2(2);
         }
         __builtin_amdgcn_sched_barrier(0);
         unit = next;

@@ -482,13 +482,23 @@ __global__ void logistic_noise_kernel(float* __restrict__ z, long long n, unsign
 // finish -- by then every block has read them -- moves the offset on by n and clears the ticket, so the next replay draws the next
 // range: the stream of pwv_logistic_noise_f32(seed, offset), (seed, offset + n), ...  skip != 0: z is the caller's, nothing moves.
 __global__ void logistic_noise_stream_kernel(float* __restrict__ z, long long n, unsigned long long* state) {
-    const unsigned long long seed = state[0], offset = state[1];
-    const bool skip = state[3] != 0;
+    // one thread reads {seed, offset, skip} with atomic loads (the last block of this very launch stores to state[1]: a plain load
+    // could legally be re-materialised behind that store) and hands them to its block through LDS; the ticket is acq_rel: a block's
+    // reads are ordered before its arrival, the last arriver's update behind everyone's
+    __shared__ unsigned long long sh[3];
+    if (threadIdx.x == 0) {
+        sh[0] = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh[1] = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh[2] = __hip_atomic_load(&state[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned long long seed = sh[0], offset = sh[1];
+    const bool skip = sh[2] != 0;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !skip) z[i] = logistic_of_counter(seed, (unsigned long long)i + offset);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long done = __hip_atomic_fetch_add(&state[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long done = __hip_atomic_fetch_add(&state[2], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (unsigned long long)gridDim.x - 1ull) {
             if (!skip) __hip_atomic_store(&state[1], offset + (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&state[2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -580,7 +590,7 @@ using namespace pwv;
 extern "C" {
 
 const char* pwv_last_error(void) { return error_buffer(); }
-int pwv_version(void) { return 200; }
+int pwv_version(void) { return PWV_HIP_VERSION; }
 
 int pwv_range_flag(int** flag) {
     static int* g_flag = nullptr;      // process lifetime; pinned + mapped: the same pointer is valid on host and device

@@ -34,7 +34,9 @@
 // Results are bit-identical to the per-layer launches (same per-unit arithmetic): tests/test_gpu_persist.py.
 #include "pwv_f16x3.h"
 
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 
 // cache policy of the stores of units no other workgroup reads (0 = plain: produced and consumed through one CU's L2)
 #ifndef PWV_PERSIST_STORE_AUX
@@ -1127,9 +1129,9 @@ int pwv_persist_status(int** status) {
     return PWV_OK;
 }
 
-struct PersistPlan { int units, nwg, per_wg, last_wg, reach_wgs, xcd_map; };
+struct PersistPlan { int units, nwg, per_wg, last_wg, reach_wgs, xcd_map, tail_reach_wgs; };
 
-static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int max_wgs, int min_units, PersistPlan& pl) {
+static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int max_wgs, int min_units, int tail_q, int tail_dil, PersistPlan& pl) {
     PWV_CHECK_ARG(G >= 1 && G <= PWV_MAX_NETS, "persistent stack: G=%d out of range", G);
     PWV_CHECK_ARG(n_layers >= 2 && n_layers <= kMaxPLayers && dil, "persistent stack: 2..%d layers per launch, got %d", kMaxPLayers, n_layers);
     PWV_CHECK_ARG(rows >= 1 && rows < (1ll << 31) - 256, "persistent stack: bad N*T");
@@ -1158,27 +1160,53 @@ static int persist_plan(int G, long long rows, int n_layers, const int* dil, int
     PWV_CHECK_ARG(pl.reach_wgs <= kMaxReachWgs, "persistent stack: dilation %d reaches over %d workgroups (max %d)", dmax, pl.reach_wgs, kMaxReachWgs);
     const int grid = G * pl.nwg;
     pl.xcd_map = (pl.nwg % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+    // the tail's layer looks back too (a stack whose LAST dilation is its largest passed the probe and failed at the launch)
+    pl.tail_reach_wgs = 0;
+    if (tail_q > 0) {
+        PWV_CHECK_ARG(tail_q <= kMaxQ && tail_dil >= 1, "persistent stack: tail_q 1..%d, tail_dilation >= 1", kMaxQ);
+        PWV_CHECK_ARG(rows * tail_q * 4 < (1ll << 32), "persistent stack: tail_out beyond the 4 GB reach of a buffer descriptor");
+        pl.tail_reach_wgs = ((tail_dil + 31) / 32 + pl.per_wg - 1) / pl.per_wg;
+        PWV_CHECK_ARG(pl.tail_reach_wgs <= kMaxReachWgs, "persistent stack: tail dilation %d reaches over %d workgroups (max %d)", tail_dil, pl.tail_reach_wgs, kMaxReachWgs);
+    }
     return PWV_OK;
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-size_t pwv_persist_workspace_bytes(const pwv_persist_args* a) {
+// The caller's struct, as far as the caller knows it (struct_size), in front of zeros: a client compiled against an earlier minor version
+// of the header passes a shorter struct, and what lies behind it in its memory is not ours to read (a garbage `status`
+// pointer would be written through on a give-up, a garbage tail_q would switch the tail on)
+static int persist_args_copy(const pwv_persist_args* a, pwv_persist_args& out, const char* who) {
+    PWV_CHECK_ARG(a, "%s: NULL argument", who);
+    const size_t need = offsetof(pwv_persist_args, min_units_per_workgroup) + sizeof(int);
+    PWV_CHECK_ARG(a->struct_size >= need, "%s: pwv_persist_args.struct_size = %zu (set it to sizeof(pwv_persist_args); at least %zu)", who,
+                  (size_t)a->struct_size, need);
+    memset(&out, 0, sizeof(out));
+    memcpy(&out, a, a->struct_size < sizeof(out) ? a->struct_size : sizeof(out));
+    return PWV_OK;
+}
+
+size_t pwv_persist_workspace_bytes(const pwv_persist_args* args) {
     PersistPlan pl;
     const int cus = device_cus();
-    if (!a) { set_error(PWV_EINVAL, "pwv_persist_workspace_bytes: NULL argument"); return 0; }
-    if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl) != PWV_OK) return 0;
+    pwv_persist_args copy;
+    if (persist_args_copy(args, copy, "pwv_persist_workspace_bytes") != PWV_OK) return 0;
+    const pwv_persist_args* a = &copy;
+    if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, a->tail_q, a->tail_dilation, pl) != PWV_OK) return 0;
     // progress words + the abort word + the exit counter (one 256-byte line) + one arrival counter per range (the tail's affine)
     return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256) + align256((size_t)pl.nwg * 4);
 }
 
-int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream) {
-    PWV_CHECK_ARG(a && a->workspace, "pwv_wavenet_stack_persist_f32: NULL args / workspace");
+int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream) {
+    pwv_persist_args copy;
+    if (int rc0 = persist_args_copy(args, copy, "pwv_wavenet_stack_persist_f32")) return rc0;
+    const pwv_persist_args* a = &copy;
+    PWV_CHECK_ARG(a->workspace, "pwv_wavenet_stack_persist_f32: NULL workspace");
     const int cus = device_cus();
     if (cus <= 0) return set_error(PWV_EHIP, "no HIP device");
     PersistParams p{};
     PersistPlan pl;
-    int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, pl);
+    int rc = persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, a->tail_q, a->tail_dilation, pl);
     if (rc != PWV_OK) return rc;
     PWV_CHECK_ARG(a->N >= 1 && a->T >= 1, "pwv_wavenet_stack_persist_f32: bad N/T");
     PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3 || a->precision == PWV_PREC_F32, "pwv_wavenet_stack_persist_f32: precision must be PWV_PREC_F16X3 or PWV_PREC_F32");
@@ -1243,8 +1271,6 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
     p.tail_q = 0;
     if (a->tail_q > 0) {
         PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3, "pwv_wavenet_stack_persist_f32: the tail (last layer + head inside the launch) exists for PWV_PREC_F16X3 only");
-        PWV_CHECK_ARG(a->tail_q <= kMaxQ && a->tail_dilation >= 1, "pwv_wavenet_stack_persist_f32: tail_q 1..%d, tail_dilation >= 1", kMaxQ);
-        PWV_CHECK_ARG((long long)a->N * a->T * a->tail_q * 4 < (1ll << 32), "pwv_wavenet_stack_persist_f32: tail_out beyond the 4 GB reach of a buffer descriptor");
         for (int g = 0; g < a->G; ++g) {
             PWV_CHECK_ARG(a->tail_layer[g] && a->tail_head[g] && a->tail_out[g], "pwv_wavenet_stack_persist_f32: NULL tail buffer for net %d", g);
             p.tail_layer[g] = a->tail_layer[g];
@@ -1253,10 +1279,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* a, pwv_stream_t stream
         }
         p.tail_q = a->tail_q;
         p.tail_dil = a->tail_dilation;
-        const int reach = (a->tail_dilation + 31) / 32;
-        p.tail_reach_wgs = (reach + pl.per_wg - 1) / pl.per_wg;
-        PWV_CHECK_ARG(p.tail_reach_wgs <= kMaxReachWgs, "pwv_wavenet_stack_persist_f32: tail dilation %d reaches over %d workgroups (max %d)",
-                      a->tail_dilation, p.tail_reach_wgs, kMaxReachWgs);
+        p.tail_reach_wgs = pl.tail_reach_wgs;
         if (a->affine_x) {
             PWV_CHECK_ARG(a->affine_out && ((a->G == 2 && a->tail_q == 1) || (a->G == 1 && a->tail_q == 2)),
                           "pwv_wavenet_stack_persist_f32: the fused affine needs affine_out and (G = 2, tail_q = 1) or (G = 1, tail_q = 2)");

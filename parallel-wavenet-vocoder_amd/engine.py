@@ -88,13 +88,35 @@ _tls = threading.local()      # .words: {device index: StatusWords};  .depth: ne
 _verify = _tls
 
 
+_free_words: List[int] = []      # pinned pairs whose owners (threads, graphs) are gone: handed out again instead of allocated
+_free_words_lock = threading.Lock()
+
+
 class StatusWords(object):
-    __slots__ = ('addr',)
+    """One pinned, mapped pair {give-up word, range word}.  Pairs are POOLED: a serving process that spawns short-lived worker
+    threads would otherwise leave one page-granular pinned allocation behind per thread.  A pair goes back to the
+    pool when its last owner is collected -- the thread's table (a thread-local) and every GraphedVocoder that captured launches
+    carrying it hold references -- and is cleared when it is handed out again.  (A launch the dead thread left in flight can
+    still raise such a pair: the next owner then sees one spurious give-up, i.e. one rerun -- never a wrong result.)"""
+    __slots__ = ('addr', '__weakref__')
 
     def __init__(self):
-        p = c_void_p()
-        check(_lib.lib().pwv_status_words_alloc(ctypes.byref(p)), 'pwv_status_words_alloc')
-        self.addr = p.value
+        with _free_words_lock:
+            addr = _free_words.pop() if _free_words else None
+        if addr is None:
+            p = c_void_p()
+            check(_lib.lib().pwv_status_words_alloc(ctypes.byref(p)), 'pwv_status_words_alloc')
+            addr = p.value
+        self.addr = addr
+        self.persist = 0
+        self.range = 0
+
+    def __del__(self):
+        try:
+            with _free_words_lock:
+                _free_words.append(self.addr)
+        except Exception:      # interpreter shutdown
+            pass
 
     def _w(self, k):
         return ctypes.c_int.from_address(self.addr + 4 * k)
@@ -145,6 +167,9 @@ _persist_cooldown = 0
 _persist_backoff = PERSIST_RETRY_AFTER
 
 
+# NOTE the suspension below is PROCESS-wide (one counter for all threads) although the sticky words are per thread: a give-up means
+# the chip is shared with somebody, which concerns every thread's launches alike; the other threads' graphs are re-captured
+# on the per-layer path at their next call (graph.GraphedVocoder._launch_mode).
 def persist_suspended() -> bool:
     return _persist_cooldown > 0
 
@@ -264,21 +289,28 @@ def _persist_runs(L: int, first: int = 1) -> List[Tuple[int, int]]:
     return runs
 
 
-def _use_persist(G: int, n: int, t: int, dilations, first: int = 1) -> bool:
+def _use_persist(G: int, n: int, t: int, dilations, first: int = 1, tail_q: int = 0) -> bool:
+    """Can layers first .. L-2 (and, with tail_q > 0, the last layer + head behind the last run) run as persistent launches?"""
     L = len(dilations)
     if PERSIST is False or _persist_cooldown > 0 or L < 4:
         return False
     if PERSIST == 'auto' and n * t > PERSIST_AUTO_MAX_ROWS:
         return False
     lib = _lib.lib()
-    for j0, cnt in _persist_runs(L, first):    # 0 bytes = the library cannot run this shape persistently: per-layer launches
+    runs = _persist_runs(L, first)
+    for j0, cnt in runs:    # 0 bytes = the library cannot run this shape persistently: per-layer launches
         pa = _lib.PersistArgs()
         pa.G, pa.n_layers, pa.N, pa.T = G, cnt, n, t
         pa.dilations = (ctypes.c_int * cnt)(*[int(d) for d in dilations[j0:j0 + cnt]])
         pa.min_units_per_workgroup = PERSIST_MIN_UNITS
+        if tail_q > 0 and (j0, cnt) == runs[-1]:      # the tail's own look-back (the LAST dilation) is part of the answer
+            pa.tail_q, pa.tail_dilation = tail_q, int(dilations[L - 1])
         if lib.pwv_persist_workspace_bytes(ctypes.byref(pa)) == 0:
             return False
     return True
+
+
+PERSIST_ARGS_HOOK = None      # tests: called with the filled-in pwv_persist_args right before every persistent launch
 
 
 def _net_streams(device):
@@ -291,6 +323,48 @@ def _net_streams(device):
 # ---- range guard of the split-fp16 arithmetic (include/pwv_hip.h, "Range guard") -------------------------------
 F16_LIMIT = 65000.0          # fp16 max is 65504; stay below the value that rounds up to inf
 _range_warned = set()
+RANGE_LOG = None             # a list: every run-time check of a split-fp16 forward appends (kind, observed max, limit, pack-time bounds)
+                             # -- diagnostics only (range_report): each entry costs a device -> host read
+
+
+def _log_range(kind: str, x: torch.Tensor, limit: float, bounds=None) -> None:
+    if RANGE_LOG is not None:
+        RANGE_LOG.append((kind, float(x.abs().max()), float(limit), bounds))
+
+
+def range_report(forward) -> dict:
+    """How far a split-fp16 forward stays from fp16's exponent range, per operand class: runs `forward()` (eager, precision 'f16x3')
+    with RANGE_LOG on and returns, per class, the limit the guard derived, the maximum it observed (run-time classes) or bounded
+    (pack-time classes), and their quotient -- `range_margin` = the smallest quotient: the factor by which every weight / input of that
+    class could grow before the guard (deliberately conservative) would send the forward to the exact-fp32 kernels.
+      weights         max |w| after the exp2 scale folding              vs 65000            (pack time)
+      residual        sum_i (||dense_i||_1 + |bias_i|) + |h|max bound   vs 65000            (pack time + observed flow input)
+      head_operand    ||skip||_1 + |bias| (relu(skip) feeds postprocess1) vs 65000          (pack time)
+      flow_input      max |x| entering a flow                           vs x_limit           (run time, checked on the device)
+      mel             max |mel|                                         vs mel_limit         (run time, checked on the device)"""
+    global RANGE_LOG
+    saved, RANGE_LOG = RANGE_LOG, []
+    try:
+        forward()
+        torch.cuda.synchronize()
+        log = RANGE_LOG
+    finally:
+        RANGE_LOG = saved
+    classes = {}
+
+    def put(name, limit, observed):
+        cur = classes.get(name)
+        q = limit / observed if observed > 0 else float('inf')
+        if cur is None or q < cur['margin']:
+            classes[name] = {'limit': limit, 'observed': observed, 'margin': q}
+
+    for kind, seen, limit, bounds in log:
+        put(kind, limit, seen)
+        for b in bounds or ():
+            put('weights', F16_LIMIT, b['w_max'])
+            put('head_operand', F16_LIMIT, b['skip_bound'])
+            put('residual', F16_LIMIT, b['res_bound'] + b['c0_max'] + b['c_causal'] * seen)
+    return {'classes': classes, 'range_margin': min((c['margin'] for c in classes.values()), default=float('inf'))}
 
 
 def range_flag_ptr() -> int:
@@ -315,8 +389,10 @@ def raise_if_range_flag(where: str = '', words: Optional[StatusWords] = None) ->
                                  % (' (%s)' % where if where else ''))
 
 
-def range_check_op(x: torch.Tensor, limit: float) -> None:
+def range_check_op(x: torch.Tensor, limit: float, kind: Optional[str] = 'mel') -> None:
     """Enqueue the check |x| <= limit (and finite) on the current stream; a violation raises the sticky flag."""
+    if kind:
+        _log_range(kind, x, limit)
     check(_lib.lib().pwv_range_check_f32(_ptr(x), x.numel(), float(limit), range_flag_ptr(), _stream()), 'pwv_range_check_f32')
 
 
@@ -587,6 +663,8 @@ class NetPlan:
         budget = F16_LIMIT - res_bound - c0_max
         self.f16x3_ok = w_max < F16_LIMIT and skip_bound < F16_LIMIT and res_bound < F16_LIMIT and budget > 0
         self.x_limit = budget / c_causal if c_causal > 0 else 3.0e38
+        # what the guard knows at pack time (range_report / tools/precision_report.py: limit vs observed per operand class)
+        self.range_bounds = {'w_max': w_max, 'res_bound': res_bound, 'skip_bound': skip_bound, 'c_causal': c_causal, 'c0_max': c0_max}
 
 
 _plan_cache: Dict[Tuple, Tuple[int, NetPlan]] = {}
@@ -618,7 +696,12 @@ def _same_structure(a, b) -> bool:
             and a.condition_channels == b.condition_channels and a.filter_width == b.filter_width)
 
 
-def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec, affine=None):
+def tail_fusable(prec: int) -> bool:
+    """Does the persistent launch of this arithmetic run the net's last layer + head (+ affine) as its tail?"""
+    return bool(FUSE_TAIL and FUSE_HEAD and prec == _lib.PREC_F16X3)
+
+
+def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec, affine=None, tail=None):
     """Layers 0 .. L-2 as ONE persistent launch (layer 0 a launch of its own when it cannot rebuild the causal layer itself), with
     layer L-1 + the head behind it -- and, given `affine` = (x, out), the flow's affine out = x*s + b -- INSIDE that launch on the
     split-fp16 path (FUSE_TAIL; otherwise one more launch for them); all nets of the flow in every launch, all on the current
@@ -652,7 +735,8 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
     rot, out_slot = 0, 2
     runs = _persist_runs(L, 1 if x_first is None else 0)
     Q = net0.out_channels
-    tail = FUSE_TAIL and FUSE_HEAD and prec == _lib.PREC_F16X3
+    if tail is None:
+        tail = tail_fusable(prec)
     affine_fused = bool(tail and affine is not None and ((G == 2 and Q == 1) or (G == 1 and Q == 2)))
     for j0, cnt in runs:
         pa = _lib.PersistArgs()
@@ -701,6 +785,8 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         if EVENT_LOG is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        if PERSIST_ARGS_HOOK is not None:
+            PERSIST_ARGS_HOOK(pa)
         check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
         if ev is not None:
             ev[1].record()
@@ -828,6 +914,8 @@ def repeat_condition_with_projections(nets: Sequence, melspec: torch.Tensor, den
     frames = torch.empty((n, t_mel, c), dtype=torch.float32, device=melspec.device)
     p_all = torch.empty((m, w_all.shape[1]), dtype=torch.float32, device=melspec.device)
     flag = range_flag_ptr() if (name == 'f16x3' and mel_limit is not None) else None
+    if flag is not None:
+        _log_range('mel', melspec, mel_limit)
     check(_lib.lib().pwv_cond_project_f32(_ptr(melspec), _ptr(dense), n_mels, _ptr(w_all), _ptr(b_all), _ptr(frames), _ptr(p_all), m, c,
                                           w_all.shape[1], float(mel_limit or 0.0), flag, _stream()), 'pwv_cond_project_f32')
     cond = RepeatedCondition(frames, hop, hop // 2, length)
@@ -908,6 +996,8 @@ def _run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str], m
             warnings.warn("pwv: weights of %s exceed the range of the split-fp16 arithmetic; using precision 'f32' for it" % (key,))
         return _run_nets(nets, x, cond, 'f32', max_workgroups, affine_out)
     x_limit = min(p.x_limit for p in plans)
+    if prec == _lib.PREC_F16X3:
+        _log_range('flow_input', x, x_limit, [p.range_bounds for p in plans])
     L = plans[0].n_layers
     for net, plan in zip(nets, plans):
         assert plan.n_layers == len(net.dilations) and plan.with_skip == bool(net.use_skip_connection)
@@ -947,8 +1037,15 @@ def _run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str], m
     # front buffer is neither written nor read
     first_fused = (FUSE_FIRST and prec in (_lib.PREC_F16X3, _lib.PREC_F32, _lib.PREC_F16) and qin == 1 and net0.filter_width == 2
                    and net0.residual_channels == 64 and not net0.use_skip_connection and plans[0].causal_bias is None)
-    persist = ((prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
-               and max_workgroups == 0 and _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1))
+    persist_able = ((prec == _lib.PREC_F32 or (prec == _lib.PREC_F16X3 and FUSE_HEAD)) and mode != 'samples' and not use_skip
+                    and max_workgroups == 0)
+    # the tail (last layer + head inside the launch) has a look-back of its own -- the stack's LAST dilation: ask for the launch that
+    # will be made, and keep the persistent layers with the tail as a launch of its own where only the tail does not fit
+    tail = bool(persist_able and tail_fusable(prec))
+    persist = persist_able and _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1, net0.out_channels if tail else 0)
+    if persist_able and tail and not persist:
+        tail = False
+        persist = _use_persist(G, n, t, net0.dilations, 0 if first_fused else 1, 0)
     two = G == 2 and TWO_STREAMS and max_workgroups == 0 and not persist
     side = _net_streams(dev) if two else None
     row_stride = 128 * L
@@ -981,7 +1078,7 @@ def _run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str], m
     # split-fp16 and fp32 kernels: layer 0 rebuilds the causal layer's output from the scalar input itself
     # (pwv_layer_args.x_first), so the [rows, 64] front buffer is neither written nor read
     if prec == _lib.PREC_F16X3 and not first_fused:
-        range_check_op(x, x_limit)          # (layer 0 checks its scalar input itself when it rebuilds the causal layer)
+        range_check_op(x, x_limit, kind=None)          # (layer 0 checks its scalar input itself when it rebuilds the causal layer)
     if first_fused:
         pass
     elif qin == 1:
@@ -1009,7 +1106,7 @@ def _run_nets(nets: Sequence, x: torch.Tensor, cond, precision: Optional[str], m
     if persist:
         aff = (x, affine_out) if (affine_out is not None and qin == 1) else None
         done = _run_stack_persist(lib, nets, plans, projs, bufs, outs, x if first_fused else None, x_limit, row_stride,
-                                  (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec, aff)
+                                  (hop, offset, frames_per_utt) if mode == 'frames' else (0, 0, 0), n, t, s, prec, aff, tail)
         return outs, done
     if two:
         for g in range(2):

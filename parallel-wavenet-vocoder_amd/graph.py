@@ -43,6 +43,7 @@ class GraphedVocoder(object):
         # (pwv_logistic_noise_stream_f32), so a forward on sampled noise is ONE graph launch and nothing else
         self.noise_state = torch.zeros((4,), dtype=torch.int64, device=self.device)
         self._noise_mirror = (0, 0, 0)          # (seed, offset, skip) the device state holds
+        self._last_drawn = 0                    # samples the replay that has not been verified yet took from the model's noise stream
         self._warmup = warmup
         self._capture()
 
@@ -82,9 +83,16 @@ class GraphedVocoder(object):
         next call re-captures on the persistent path again (_launch_mode)."""
         try:
             engine.verify_enqueued(words=self._words)
-        except engine._lib.PwvPersistError:
-            self._capture()
+        except engine._lib.PwvError as e:
+            # the replay that failed drew its noise from the stream already: hand that range back, so that the caller's rerun
+            # (z = None again) is a rerun ON THE SAME NOISE, like the eager path's (the device state is rewritten by the next call:
+            # its mirror no longer matches)
+            self.model.noise_offset -= self._last_drawn
+            self._last_drawn = 0
+            if isinstance(e, engine._lib.PwvPersistError):
+                self._capture()
             raise
+        self._last_drawn = 0
 
     def __call__(self, melspec: torch.Tensor, z: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> torch.Tensor:
         """melspec [N, t_mel, n_mels] -- copied into the graph's input buffer, or that buffer itself (`graphed.mel`, filled by the caller:
@@ -106,10 +114,12 @@ class GraphedVocoder(object):
             self._set_noise_state(want)
             numel = self.z.numel()
             self.model.noise_offset += numel
+            self._last_drawn = numel
             self._noise_mirror = (want[0], want[1] + numel, 0)
         else:
             if tuple(z.shape) != tuple(self.z.shape):
                 raise ValueError('z must be %s, got %s' % (tuple(self.z.shape), tuple(z.shape)))
+            self._last_drawn = 0
             self._set_noise_state((self._noise_mirror[0], self._noise_mirror[1], 1))      # skip: z is the caller's
             if z is not self.z:
                 self.z.copy_(z, non_blocking=True)
@@ -118,5 +128,7 @@ class GraphedVocoder(object):
 
     def _set_noise_state(self, want):
         if want != self._noise_mirror:
-            self.noise_state.copy_(torch.tensor([want[0], want[1], 0, want[2]], dtype=torch.int64), non_blocking=False)
+            # the state words are uint64 on the device (seeds up to 2**64 - 1, like the eager sampler's c_uint64): same bits as int64
+            wrap = lambda v: (int(v) & ((1 << 64) - 1)) - (1 << 64) if (int(v) & (1 << 63)) else int(v) & ((1 << 64) - 1)  # noqa: E731
+            self.noise_state.copy_(torch.tensor([wrap(want[0]), wrap(want[1]), 0, want[2]], dtype=torch.int64), non_blocking=False)
             self._noise_mirror = want

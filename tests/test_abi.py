@@ -28,7 +28,7 @@ def test_header_symbols_exported(built_lib):
 def test_packed_sizes_and_column_map(built_lib):
     from pwv_amd import _lib
     lib = built_lib
-    assert lib.pwv_version() >= 100
+    assert lib.pwv_version() == _lib.HEADER_VERSION == 300      # PWV_HIP_VERSION: 3xx = pwv_persist_args begins with struct_size
     base = lib.pwv_layer_packed_floats(0, 0)
     assert base == 4 * 16 * 64 * 4 + 2 * 8 * 64 * 4 + 64               # filter|gate + dense + dense bias
     assert lib.pwv_layer_packed_floats(1, 0) == base + 8192 + 128     # + skip + skip bias
@@ -57,6 +57,15 @@ def test_argument_validation_no_gpu(built_lib):
     assert lib.pwv_pack_layer_f32(1, 1, 1, None, None, None, None, None, 0, 40, 0, 1, None) == -1   # cond C != 80
     with pytest.raises(_lib.PwvError):
         _lib.check(-1, 'x')
+    # pwv_persist_args carries its own size (PWV_HIP_VERSION 3xx): a struct that does not say how long it is is refused before
+    # anything in it is used; the ctypes mirror fills the field in by itself
+    pa = _lib.PersistArgs()
+    assert pa.struct_size == ctypes.sizeof(_lib.PersistArgs)
+    pa.struct_size = 0
+    assert lib.pwv_persist_workspace_bytes(ctypes.byref(pa)) == 0 and b'struct_size' in lib.pwv_last_error()
+    pa.struct_size = 16
+    assert lib.pwv_persist_workspace_bytes(ctypes.byref(pa)) == 0 and b'struct_size' in lib.pwv_last_error()
+    assert lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), None) == -1 and b'struct_size' in lib.pwv_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -248,3 +248,69 @@ def test_auto_policy_takes_the_persistent_launch_where_the_library_supports_the_
     assert not engine._use_persist(2, 1, 3200, [1, 2, 4, 4096, 8, 16])       # 129 units back at one unit per workgroup
     engine.PERSIST = False
     assert not engine._use_persist(2, 1, 16000, D10)
+
+
+def test_a_shorter_callers_struct_is_not_read_past_its_end(gpu, persist_knobs):
+    """pwv_persist_args grew by appended fields.  A client compiled against an earlier minor version passes a SHORTER struct
+    (struct_size says how short); what lies behind it in the caller's memory -- here: a wild status pointer, tail_q = 3 with wild tail pointers,
+    a wild affine_x -- must be treated as zero.  The launch then is the plain run of residual layers, bit-identical to the per-layer path."""
+    import torch
+    from pwv_amd import _lib
+    engine = persist_knobs
+    store, nets = _nets(gpu, 10, 2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 16000, 1), generator=g).to(gpu)
+    cond = engine.RepeatedCondition(torch.rand((1, 201, 80), generator=g).to(gpu), 80, 40, 16000)
+    engine.PERSIST = False
+    ref = [o.clone() for o in engine.run_nets(nets, x, cond, precision='f16x3')]
+    engine.PERSIST, engine.FUSE_TAIL = True, False      # (the engine itself does not ask for the tail: the fields are free for garbage)
+    seen = []
+
+    def truncate(pa):
+        pa.struct_size = _lib.PersistArgs.status.offset      # the struct as it was before the status word, the tail and the affine were appended
+        pa.status = 0xdead0000
+        pa.tail_q, pa.tail_dilation = 3, 7
+        for k in range(2):
+            pa.tail_layer[k] = pa.tail_head[k] = pa.tail_out[k] = 0xdead0000
+        pa.affine_x = pa.affine_out = 0xdead0000
+        seen.append(pa.struct_size)
+
+    engine.PERSIST_ARGS_HOOK = truncate
+    try:
+        got = engine.run_nets(nets, x, cond, precision='f16x3')
+        torch.cuda.synchronize()
+    finally:
+        engine.PERSIST_ARGS_HOOK = None
+    assert seen and engine.persist_status() == 0
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
+def test_a_tail_that_reaches_too_far_runs_as_its_own_launch(gpu, persist_knobs):
+    """the probe behind `_use_persist` asks about the launch that will be made, tail included.  A stack whose LAST dilation is
+    its largest (2048 samples = 64 units, one unit per workgroup: 64 workgroups back, the poll reaches 60) keeps its persistent layers and
+    runs last layer + head as a launch of their own -- it used to pass the probe and fail at the launch."""
+    import torch
+    from pwv_amd.modules import WaveNet
+    from pwv_amd.variables import VariableStore
+    engine = persist_knobs
+    store = VariableStore(device=gpu, seed=4)
+    kw = dict(batch_size=1, dilations=[1, 2, 4, 8, 16, 2048], filter_width=2, residual_channels=64, dilation_channels=64, skip_channels=128,
+              quantization_channels=1, use_biases=True, condition_channels=80, use_skip_connection=False, is_training=False, store=store)
+    nets = [WaveNet(name='n%d' % k, **kw) for k in range(2)]
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((1, 4000, 1), generator=g).to(gpu)      # 125 units on 128 workgroups per net: one unit each
+    cond = engine.RepeatedCondition(torch.rand((1, 51, 80), generator=g).to(gpu), 80, 40, 4000)
+    engine.PERSIST = False
+    ref = [o.clone() for o in engine.run_nets(nets, x, cond, precision='f16x3')]
+    engine.PERSIST, engine.PERSIST_MIN_UNITS = True, 1
+    assert not engine._use_persist(2, 1, 4000, kw['dilations'], 0, tail_q=1) and engine._use_persist(2, 1, 4000, kw['dilations'], 0, tail_q=0)
+    log = engine.EVENT_LOG = []
+    try:
+        got = engine.run_nets(nets, x, cond, precision='f16x3')
+        torch.cuda.synchronize()
+    finally:
+        engine.EVENT_LOG = None
+    assert engine.persist_status() == 0 and [e[0] for e in log] == ['persist'] and log[0][6] == 0      # persistent layers, no tail in the launch
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)

@@ -375,6 +375,56 @@ def test_graphed_vocoder_recaptures_when_the_engine_switches_launch_paths(gpu):
         engine.resume_persist()
 
 
+def test_graphed_rerun_after_a_failed_verify_draws_the_same_noise_and_large_seeds_work(gpu):
+    """the sampler is a node of the graph and the model's noise offset moves on when a replay is ENQUEUED; a verify() that
+    fails must hand the range back, so that the prescribed rerun (z = None again) is a rerun on the same noise, as on the eager path.  And a
+    seed >= 2**63 -- accepted by the eager sampler (uint64) -- must reach the device state with the same bits."""
+    import torch
+    from pwv_amd import engine
+    from pwv_amd._lib import PwvPersistError, PwvRangeError
+    from pwv_amd.graph import GraphedVocoder
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    from tests.util import small_cfg
+    cfg = small_cfg()
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=4))
+    n, length = 2, 480
+    model = IAFVocoder(batch_size=n, length=length, store=store)
+    mel = torch.from_numpy(O.synthetic_inputs(n, length, cfg)[0]).to(gpu)
+    graphed = GraphedVocoder(model)
+    try:
+        big = (1 << 63) + 12345
+        model.noise_seed, off = big, model.noise_offset
+        first = graphed(mel).clone()
+        graphed.verify()
+        z0 = engine.logistic_noise_op((n, length, 1), gpu, seed=big, offset=off)
+        assert torch.equal(first, model(None, mel, is_training=False, z=z0))
+        # a replay whose verification fails (the range word poked from the host; a real one needs an out-of-range mel) ...
+        off = model.noise_offset
+        failed = graphed(mel).clone()
+        engine.current_words().range = 1
+        with pytest.raises(PwvRangeError):
+            graphed.verify()
+        assert model.noise_offset == off                                      # ... has handed its noise range back
+        again = graphed(mel).clone()
+        graphed.verify()
+        assert torch.equal(again, failed) and model.noise_offset == off + n * length
+        # ... the same after a give-up (the graph is re-captured on the per-layer path: same noise, same bits by the cross-path identity)
+        off = model.noise_offset
+        failed = graphed(mel).clone()
+        engine.poke_persist_status(4)
+        with pytest.raises(PwvPersistError):
+            graphed.verify()
+        assert model.noise_offset == off
+        again = graphed(mel).clone()
+        graphed.verify()
+        assert torch.equal(again, failed)
+    finally:
+        engine.resume_persist()
+
+
 def test_bench_multi_rank_control_flow_on_one_gpu():
     """bench.py for N > 1, both ways it can be started -- under torch.distributed.run (one process per rank) and plainly
     (`python bench.py --gpus 2`: it then spawns its ranks itself) -- with the test hook PWV_BENCH_DRYRUN_ONE_GPU=1: both

@@ -322,3 +322,60 @@ def test_two_threads_on_two_streams_do_not_see_each_others_flags(gpu):
     msgs = [str(w.message) for w in caught if str(w.message).startswith('pwv:')]
     assert len(msgs) == 6 and all('exact fp32' in m for m in msgs)                       # exactly A's six repairs, nothing for B
     assert not engine.range_flag_raised() and engine.persist_status() == 0               # (this thread's words: untouched)
+
+
+@pytest.mark.gpu
+def test_status_words_of_finished_threads_are_pooled(gpu):
+    """every thread gets its own pinned pair of sticky words; a serving process that spawns short-lived workers must not
+    leave one pinned allocation behind per worker.  A pair returns to the pool when its thread (and every graph that captured it) is gone,
+    and comes out of it cleared."""
+    import gc
+    import threading
+    from pwv_amd import engine
+    addrs = []
+
+    def worker():
+        w = engine.current_words(gpu)
+        w.range = 1                      # left raised: the next owner must not see it
+        addrs.append(w.addr)
+
+    for _ in range(4):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        gc.collect()
+    assert len(set(addrs)) < len(addrs), addrs          # later threads were handed pairs of earlier ones
+    fresh = []
+    t = threading.Thread(target=lambda: fresh.append((engine.current_words(gpu).addr, engine.current_words(gpu).range, engine.current_words(gpu).persist)))
+    t.start()
+    t.join()
+    assert fresh[0][0] in addrs and fresh[0][1:] == (0, 0)
+
+
+@pytest.mark.gpu
+def test_default_model_stays_a_decade_inside_the_range_guard(gpu):
+    """the margin between what the split-fp16 range guard allows and what the default model shows on the inputs every
+    parity test and bench.py use (glorot weights, N(0, 0.1) biases, logistic noise, mel in [-1, 1]) -- limit / observed per operand class
+    (engine.range_report) -- is at least 10x, i.e. the fast arithmetic is not one unlucky sample away from the exact-fp32 rerun.
+    (tools/precision_report.py --range prints the table, also for a trained-like weight set: DESIGN.md section 2.)"""
+    import torch
+    from oracle import iaf_oracle as O
+    from pwv_amd import engine
+    from pwv_amd.models import IAFVocoder
+    from pwv_amd.variables import VariableStore
+    from tests.util import set_hparams
+    cfg = O.ModelConfig()
+    set_hparams(cfg)
+    store = VariableStore(device=gpu)
+    store.load_dict(O.init_weights(cfg, seed=2))
+    n, length = 1, 4000
+    mel_np, z_np = O.synthetic_inputs(n, length, cfg)
+    mel, z = torch.from_numpy(mel_np).to(gpu), torch.from_numpy(z_np).to(gpu)
+    model = IAFVocoder(batch_size=n, length=length, store=store, precision='f16x3')
+    rep = engine.range_report(lambda: model(None, mel, is_training=False, z=z, verify=False))
+    model.verify()
+    assert set(rep['classes']) >= {'weights', 'residual', 'head_operand', 'flow_input', 'mel'}, rep
+    assert rep['range_margin'] >= 10.0, rep
+    assert rep['range_margin'] == min(c['margin'] for c in rep['classes'].values())
+    # the report is diagnostics: with the log off nothing is read back
+    assert engine.RANGE_LOG is None
