@@ -693,6 +693,11 @@ def main():
             # per-sample condition: every layer also reads the [rows, C] condition (fp32 tile32 / fp16 hi+lo planes: 4 B per
             # channel; fp16 mode: 2 B) -- SURVEY.md section 8d, cond_b = C * b
             layer_bytes += int(hp.model.condition_channels) * (2 if args.precision == 'f16' else 4)
+        skip_all = bool(hp.model.use_skip_connection)
+        layer_flop = LAYER_FLOP_PER_SAMPLE + (2 * 64 * 128 if skip_all else 0)      # (skip 64 -> 128 in EVERY layer, modules.py:243-250)
+        if skip_all:
+            # the skip sum [rows, 128] fp32 is read and written by every layer (modules.py:147: the sum over all layers' skip outputs)
+            layer_bytes += 2 * 128 * 4
         if timing is not None and timing['kind'] == 'persist':
             # the dominant kernel is the persistent stack kernel: one launch runs `layers` residual layers of both nets of a flow
             # over all timed launches; a run that starts with the net's layer 0 reads 4 B per sample there instead of a 256 B row
@@ -752,7 +757,7 @@ def main():
             # scalar / shifter chains on two streams: the measured overlap of the chains' busy intervals (sum / union) says
             # how many launches of this kernel share the chip on average
             concurrent = timing['overlap']
-            flop_per_launch = rows * nets_per_launch * LAYER_FLOP_PER_SAMPLE
+            flop_per_launch = rows * nets_per_launch * layer_flop
             bytes_per_launch = rows * nets_per_launch * layer_bytes
             ach_tf = concurrent * flop_per_launch / (layer_ms * 1e-3) / 1e12
             ach_gbs = concurrent * bytes_per_launch / (layer_ms * 1e-3) / 1e9
@@ -779,7 +784,8 @@ def main():
                                            'frac': ach_tf / PEAK_F16_MFMA_TFLOPS}
             else:
                 # split-fp16 MFMA: 3 x 80 = 240 fp16-FLOP/B < fp16 machine balance (312) => HBM bound
-                result['roofline'] = dict(kernel='layer_f16x3_kernel<0,%d,0> (fused gated-residual layer%s, %d nets/launch)' % (per_sample, ', per-sample condition' if per_sample else '', nets_per_launch),
+                result['roofline'] = dict(kernel='layer_f16x3_kernel<%d,%d,0> (fused gated-residual layer%s%s, %d nets/launch)' % (int(skip_all), per_sample, ', per-sample condition' if per_sample else '',
+                                                 ', skip sum read-modify-written in every layer (1024 B per sample on top of the 512)' if skip_all else '', nets_per_launch),
                                           bound='hbm', achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s',
                                           frac=ach_gbs / PEAK_HBM_GBS, **common)
                 attach_profile(result['roofline'], args, rows)

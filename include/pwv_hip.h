@@ -454,7 +454,7 @@ typedef struct pwv_persist_args {
     /* optional: this call's own sticky give-up word (pwv_status_words_alloc: words[0]); NULL = the process-wide word of
      * pwv_persist_status.  Two threads / streams with their own words cannot consume or clear each other's flags. */
     int* status;
-    /* optional TAIL (PWV_PREC_F16X3, tail_q > 0; the run must be the LAST run of the stack): behind the run's layers every
+    /* optional TAIL (tail_q > 0, either arithmetic; the run must be the LAST run of the stack): behind the run's layers every
      * workgroup runs the net's last layer (dilation tail_dilation, packed weights tail_layer[g], P columns proj[g] + 128*n_layers)
      * with the post-processing head behind it (tail_head[g] = pwv_pack_head_f32's output; modules.py:145-165) on its own rows and
      * writes tail_out[g] [N*T, tail_q] -- what pwv_wavenet_layer_f32 with head_packed / head_out computes, bit for bit, without

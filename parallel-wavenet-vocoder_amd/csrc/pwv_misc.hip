@@ -61,9 +61,12 @@ __global__ void causal_conv_kernel(const float* __restrict__ x, const float* __r
 // models.py:110-120,128-130 and the hoisted modules.py:216-228.
 // --------------------------------------------------------------------------------------
 template <int KH4>  // K/2 in units of 4 floats (K = 8*KH4)
+// conv_T > 0: the two-tap dilated causal convolution of modules.causal_conv (modules.py:11-43) as this GEMM: K = 2 Cin, the lower lane
+// half (k < Cin, tap 0) reads row m - conv_d of x [M, Cin] (zeros left of the utterance start, t = m % conv_T < conv_d), the upper half row m
+// (round 6: the composed WaveNet path's convolutions ran on the scalar causal_conv_kernel at 2.7 TFLOP/s)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y, int M,
-                                                     int K, int Nout, int relu) {
+                                                     int K, int Nout, int relu, int conv_T = 0, int conv_d = 0) {
     __shared__ __attribute__((aligned(16))) float lds[4 * KH4 * 64 * 4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,10 +106,16 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
         const bool mvalid = m < M;
         const int mc = mvalid ? m : M - 1;
         float xb[KH4 * 4];
+        const float* xr = x + (size_t)mc * K + h * kh;
+        bool keep = true;
+        if (conv_T > 0) {
+            keep = h == 1 || (mc % conv_T) >= conv_d;
+            xr = x + (size_t)(mc - ((h == 0 && keep) ? conv_d : 0)) * kh;
+        }
 #pragma unroll
         for (int g = 0; g < KH4; ++g) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (4 * g < kh) v = *reinterpret_cast<const f32x4*>(x + (size_t)mc * K + h * kh + 4 * g);
+            if (4 * g < kh && keep) v = *reinterpret_cast<const f32x4*>(xr + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) xb[4 * g + e] = v[e];
         }
@@ -629,6 +638,9 @@ int pwv_device_cus(void) {
     return c > 0 ? c : set_error(PWV_EHIP, "no HIP device available");
 }
 
+static int launch_linear(const float* x, const float* w, const float* bias, float* y, int M, int K, int Nout, int relu, int conv_T, int conv_d,
+                         pwv_stream_t stream);
+
 int pwv_causal_conv_f32(const float* x, const float* filt, float* y, int N, int T, int Cin, int Cout, int W,
                         int dilation, pwv_stream_t stream) {
     PWV_CHECK_ARG(x && filt && y, "pwv_causal_conv_f32: NULL pointer");
@@ -637,6 +649,12 @@ int pwv_causal_conv_f32(const float* x, const float* filt, float* y, int N, int 
     PWV_CHECK_ARG(x != y, "pwv_causal_conv_f32: in-place not supported");
     const long long total = (long long)N * T * ((Cout + 3) / 4);
     if (total == 0) return PWV_OK;
+    // the shapes of a WaveNet's own convolutions run on the fp32 MFMA GEMM (exact fp32 products, the k order of a GEMM instead of the
+    // scalar kernel's tap-major fma chain): 1 x 1 convolutions as they are, two-tap dilated ones with the shifted row as the lower half of K
+    if ((long long)N * T < (1ll << 31) && Cout % 4 == 0 && x != y) {
+        if (W == 1 && Cin % 8 == 0 && Cin <= 128) return launch_linear(x, filt, nullptr, y, N * T, Cin, Cout, 0, 0, 0, stream);
+        if (W == 2 && Cin % 4 == 0 && Cin <= 64) return launch_linear(x, filt, nullptr, y, N * T, 2 * Cin, Cout, 0, T, dilation, stream);
+    }
     hipLaunchKernelGGL(causal_conv_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, filt, y,
                        N, T, Cin, Cout, W, dilation);
     PWV_CHECK_HIP(hipGetLastError());
@@ -648,6 +666,11 @@ int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y, 
     PWV_CHECK_ARG(x && w && y, "pwv_linear_f32: NULL pointer");
     PWV_CHECK_ARG(M >= 0 && K >= 8 && K % 8 == 0 && K <= 128, "pwv_linear_f32: K must be a multiple of 8 in [8,128], got %d", K);
     PWV_CHECK_ARG(Nout >= 4 && Nout % 4 == 0, "pwv_linear_f32: Nout must be a multiple of 4, got %d", Nout);
+    return launch_linear(x, w, bias, y, M, K, Nout, relu, 0, 0, stream);
+}
+
+static int launch_linear(const float* x, const float* w, const float* bias, float* y, int M, int K, int Nout, int relu, int conv_T, int conv_d,
+                         pwv_stream_t stream) {
     if (M == 0) return PWV_OK;
     const int kh = K / 2;   // floats per lane half, loaded as float4 chunks
     // one workgroup per (row chunk, 128-column block); ~4 workgroups per CU overall
@@ -659,11 +682,11 @@ int pwv_linear_f32(const float* x, const float* w, const float* bias, float* y, 
     dim3 grid(gx, gy), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (kh <= 32)
-        hipLaunchKernelGGL((linear_kernel<8>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+        hipLaunchKernelGGL((linear_kernel<8>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu, conv_T, conv_d);
     else if (kh <= 40)
-        hipLaunchKernelGGL((linear_kernel<10>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+        hipLaunchKernelGGL((linear_kernel<10>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu, conv_T, conv_d);
     else
-        hipLaunchKernelGGL((linear_kernel<16>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu);
+        hipLaunchKernelGGL((linear_kernel<16>), grid, block, 0, s, x, w, bias, y, M, K, Nout, relu, conv_T, conv_d);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

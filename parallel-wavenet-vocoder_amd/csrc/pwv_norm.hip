@@ -256,7 +256,9 @@ int pwv_range_stats_f32(const float* filter, const float* gate, const float* den
 
 size_t pwv_instance_norm_workspace_bytes(int N, int T, int C) {
     if (N < 1 || T < 1 || C < 1) return 0;
-    int chunks = (T + 2047) / 2048;
+    // time chunks of >= 64 rows, as many as it takes to put a block on every CU (round 6: chunks of 2048 rows left a 16000-sample
+    // utterance to 8 blocks -- 165 us per call on a chip that reads the tensor in 2; profiles/r06_configs.md, bench/in)
+    int chunks = (T + 63) / 64;
     if (chunks > kInMaxChunks) chunks = kInMaxChunks;
     return (size_t)N * chunks * C * 2 * sizeof(double);
 }
@@ -266,7 +268,9 @@ int pwv_instance_norm_f32(const float* x, float* y, int N, int T, int C, const f
     PWV_CHECK_ARG(x && y && workspace, "pwv_instance_norm_f32: NULL pointer");
     PWV_CHECK_ARG(N >= 1 && T >= 1 && C >= 1 && C <= 4096, "pwv_instance_norm_f32: bad shape N=%d T=%d C=%d", N, T, C);
     PWV_CHECK_ARG(workspace_bytes >= pwv_instance_norm_workspace_bytes(N, T, C), "pwv_instance_norm_f32: workspace too small");
-    int chunks = (T + 2047) / 2048;
+    // time chunks of >= 64 rows, as many as it takes to put a block on every CU (round 6: chunks of 2048 rows left a 16000-sample
+    // utterance to 8 blocks -- 165 us per call on a chip that reads the tensor in 2; profiles/r06_configs.md, bench/in)
+    int chunks = (T + 63) / 64;
     if (chunks > kInMaxChunks) chunks = kInMaxChunks;
     const int chunk_len = (T + chunks - 1) / chunks;
     chunks = (T + chunk_len - 1) / chunk_len;

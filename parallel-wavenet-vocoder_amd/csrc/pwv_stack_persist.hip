@@ -84,7 +84,7 @@ struct PersistParams {
     float x_limit;                         // range guard of the split-fp16 arithmetic on x_first (include/pwv_hip.h)
     int* range_flag;
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
-    // TAIL (split-fp16 only; tail_q > 0): behind the run's layers every workgroup runs the net's LAST layer with the post-processing
+    // TAIL (tail_q > 0; both arithmetics since round 6): behind the run's layers every workgroup runs the net's LAST layer with the post-processing
     // head behind it on its own units (layer_f16x3_kernel's HEAD variant, the same operations) -- and, with `pair`, the IAF affine
     const float* tail_layer[PWV_MAX_NETS]; // the last layer's packed weights (its filter|gate fragments are used)
     const float* tail_head[PWV_MAX_NETS];  // the packed head
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     // units are handed out statically, the left neighbours' progress words are polled directly, and the exit accounting at
     // the bottom is done by one thread behind a barrier.
     bool tail_done = false;
-    if constexpr (!F32) {
+    {
         if (p.tail_q > 0) {
             tail_done = true;
             __syncthreads();                       // every wave of the workgroup is out of the task loop (its stores drained, its layers left)
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 const f16x8* A1 = reinterpret_cast<const f16x8*>(lds);
                 const f16x8* HS = reinterpret_cast<const f16x8*>(lds + kHS);
                 const f16x8* H1 = reinterpret_cast<const f16x8*>(lds + kH1);
+                (void)A1; (void)HS; (void)H1;
                 const float* hb = p.tail_head[net];
                 const int Q = p.tail_q;
                 const int so = in_soff(L);         // the run's last layer wrote buffer (L - 1 + rot) % 3
@@ -936,83 +937,133 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                                 for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                             }
                     }
-                    f16x8 bh[8], bl[8];
-                    float xc[32];
+                    f32x16 acc1[4];      // postprocess1's accumulators: what both arithmetics hand to the postprocess2 dot below
+                    if constexpr (F32) {
+                        // ---- exact fp32 (round 6): the operations of layer_f32_kernel<8, ..., GATED, HEAD> in the same order ----------
+                        auto bx = [&](int ks) -> float { return ks < 32 ? txb[ks] : txc[ks - 32]; };
+                        float o[32];
+                        f32x4 a[4];
+                        a[0] = frag(lds, 0, 0, 16, 0, lane);
+                        a[1] = frag(lds, 0, 2, 16, 0, lane);
+                        gemm_groups<16, 2, 0, 2>(lds, 0, lane, acc, a, bx, no_extra, [&](f32x4(&nf)[4]) {
+                            nf[0] = frag(lds, 0, 1, 16, 0, lane);
+                            nf[1] = frag(lds, 0, 3, 16, 0, lane);
+                        });
+                        gemm_groups<16, 2, 1, 2>(
+                            lds, 0, lane, acc, a, bx,
+                            [&](int g) {
+                                o[g] = gate_act(acc[0][g], acc[2][g]);
+                                asm volatile("" : "+v"(o[g]));
+                            },
+                            [&](f32x4(&nf)[4]) {
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) xc[i] = txc[i];
-                    split8<0>(txb, bh[0], bl[0]);
-                    split8<8>(txb, bh[1], bl[1]);
-                    split8<16>(txb, bh[2], bl[2]);
-                    split8<24>(txb, bh[3], bl[3]);
-                    auto bxh = [&](int s) -> f16x8 { return bh[s]; };
-                    auto bxl = [&](int s) -> f16x8 { return bl[s]; };
-                    float o[32];
-                    f16x8 oh[4], ol[4];
-                    f16x8 ah[4], al[4];
-                    first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
-                    gemm16<8, 2, 0, 2, 4>(
-                        A1, lane, acc, ah, al, bxh, bxl,
-                        [&](int s) {
-                            if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
-                            if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
-                            if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
-                            if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
-                        },
-                        [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
-                    gemm16<8, 2, 1, 2, 4>(
-                        A1, lane, acc, ah, al, bxh, bxl,
-                        [&](int s) {
-                            o[2 * s] = gate_act(acc[0][2 * s], acc[2][2 * s]);
-                            o[2 * s + 1] = gate_act(acc[0][2 * s + 1], acc[2][2 * s + 1]);
-                            asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
-                            if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
-                            if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
-                        },
-                        [](f16x8(&)[4], f16x8(&)[4]) {});
-                    // ---- head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2 ---------------------------
-                    f32x16 accs[4];
+                                for (int i = 0; i < 4; ++i) nf[i] = frag(lds, kHS, i, 8, 0, lane);
+                            });
+                        f32x16 accs[4];
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
+                        for (int it = 0; it < 4; ++it)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHBS + h * 64 + it * 16 + q * 4);
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHBS + h * 64 + it * 16 + q * 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                                for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                            }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+                        gemm_groups<8, 4, 0, 1>(lds, kHS, lane, accs, a, [&](int ks) -> float { return o[ks]; }, no_extra, [&](f32x4(&nf)[4]) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) nf[i] = frag(lds, kH1, i, 16, 0, lane);
+                        });
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHB1 + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = v[e];
+                            }
+                        gemm_groups<16, 4, 0, 1>(lds, kH1, lane, acc1, a, [&](int ks) -> float { return fmaxf(accs[ks >> 4][ks & 15], 0.f); }, no_extra,
+                                                 [](f32x4(&)[4]) {});
+                    } else {
+                        f16x8 bh[8], bl[8];
+                        float xc[32];
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) xc[i] = txc[i];
+                        split8<0>(txb, bh[0], bl[0]);
+                        split8<8>(txb, bh[1], bl[1]);
+                        split8<16>(txb, bh[2], bl[2]);
+                        split8<24>(txb, bh[3], bl[3]);
+                        auto bxh = [&](int s) -> f16x8 { return bh[s]; };
+                        auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+                        float o[32];
+                        f16x8 oh[4], ol[4];
+                        f16x8 ah[4], al[4];
+                        first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
+                        gemm16<8, 2, 0, 2, 4>(
+                            A1, lane, acc, ah, al, bxh, bxl,
+                            [&](int s) {
+                                if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
+                                if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
+                                if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
+                                if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+                            },
+                            [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
+                        gemm16<8, 2, 1, 2, 4>(
+                            A1, lane, acc, ah, al, bxh, bxl,
+                            [&](int s) {
+                                o[2 * s] = gate_act(acc[0][2 * s], acc[2][2 * s]);
+                                o[2 * s + 1] = gate_act(acc[0][2 * s + 1], acc[2][2 * s + 1]);
+                                asm volatile("" : "+v"(o[2 * s]), "+v"(o[2 * s + 1]));
+                                if (s == 3) { split8<0>(o, oh[0], ol[0]); asm volatile("" : "+v"(oh[0]), "+v"(ol[0])); }
+                                if (s == 7) { split8<8>(o, oh[1], ol[1]); asm volatile("" : "+v"(oh[1]), "+v"(ol[1])); }
+                            },
+                            [](f16x8(&)[4], f16x8(&)[4]) {});
+                        // ---- head: o (registers) -> skip -> relu -> postprocess1 -> relu -> postprocess2 ---------------------------
+                        f32x16 accs[4];
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHBS + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) accs[it][q * 4 + e] = v[e];
+                            }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
+                        split8<16>(o, oh[2], ol[2]);
+                        split8<24>(o, oh[3], ol[3]);
+                        first_frags<4, 4, 0, 1, 4>(HS, lane, ah, al);
+                        gemm16<4, 4, 0, 1, 4>(HS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; }, no_extra,
+                                              [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 4, 0, 1, 4>(H1, lane, nh, nl); });
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHB1 + h * 64 + it * 16 + q * 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = v[e];
+                            }
+                        f16x8 sh[8], sl[8];
+                        {
+                            float r[64];
+#pragma unroll
+                            for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
+                            split8<0>(r, sh[0], sl[0]);
+                            split8<8>(r, sh[1], sl[1]);
+                            split8<16>(r, sh[2], sl[2]);
+                            split8<24>(r, sh[3], sl[3]);
+                            split8<32>(r, sh[4], sl[4]);
+                            split8<40>(r, sh[5], sl[5]);
+                            split8<48>(r, sh[6], sl[6]);
+                            split8<56>(r, sh[7], sl[7]);
                         }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[16 + r] = gate_act(acc[1][r], acc[3][r]);
-                    split8<16>(o, oh[2], ol[2]);
-                    split8<24>(o, oh[3], ol[3]);
-                    first_frags<4, 4, 0, 1, 4>(HS, lane, ah, al);
-                    gemm16<4, 4, 0, 1, 4>(HS, lane, accs, ah, al, [&](int s) -> f16x8 { return oh[s]; }, [&](int s) -> f16x8 { return ol[s]; }, no_extra,
-                                          [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 4, 0, 1, 4>(H1, lane, nh, nl); });
-                    f32x16 acc1[4];
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(hb + kHB1 + h * 64 + it * 16 + q * 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc1[it][q * 4 + e] = v[e];
-                        }
-                    f16x8 sh[8], sl[8];
-                    {
-                        float r[64];
-#pragma unroll
-                        for (int i = 0; i < 64; ++i) r[i] = fmaxf(accs[i >> 4][i & 15], 0.f);
-                        split8<0>(r, sh[0], sl[0]);
-                        split8<8>(r, sh[1], sl[1]);
-                        split8<16>(r, sh[2], sl[2]);
-                        split8<24>(r, sh[3], sl[3]);
-                        split8<32>(r, sh[4], sl[4]);
-                        split8<40>(r, sh[5], sl[5]);
-                        split8<48>(r, sh[6], sl[6]);
-                        split8<56>(r, sh[7], sl[7]);
+                        gemm16<8, 4, 0, 1, 4>(H1, lane, acc1, ah, al, [&](int s) -> f16x8 { return sh[s]; }, [&](int s) -> f16x8 { return sl[s]; }, no_extra,
+                                              [](f16x8(&)[4], f16x8(&)[4]) {});
                     }
-                    gemm16<8, 4, 0, 1, 4>(H1, lane, acc1, ah, al, [&](int s) -> f16x8 { return sh[s]; }, [&](int s) -> f16x8 { return sl[s]; }, no_extra,
-                                          [](f16x8(&)[4], f16x8(&)[4]) {});
                     load_tail(next, txb, txc);      // the next unit's rows: in flight under the postprocess2 dot
                     float outv[kMaxQ] = {0.f, 0.f, 0.f, 0.f};
+                    int out_idx = row * Q;      // (made here, behind the GEMMs, and opaque: as a loop-carried induction variable it is one register too many
+                    asm volatile("" : "+v"(out_idx));      //  for the exact-fp32 instantiation, which then spills it)
                     for (int q = 0; q < Q; ++q) {
                         float part = 0.f;
                         const float* w2 = hb + kHW2 + (h * Q + q) * 64;
@@ -1029,7 +1080,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         part += hb[kHW2 + 2 * Q * 64 + q];
                         if (q < kMaxQ) outv[q] = part;
                         // (write-through: with `pair` the other net's workgroup of this range may be the one that reads it)
-                        if (valid && h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part), out_rs, (row * Q + q) * 4, 0, kAuxWriteThrough);
+                        if (valid && h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part), out_rs, (out_idx + q) * 4, 0, kAuxWriteThrough);
                     }
                     if (p.affine_x && p.G == 1 && Q == 2) {      // one net with two outputs (scale, shift): the affine right here
                         if (valid && h == 0) p.affine_out[row] = fmaf(p.affine_x[row], outv[0], outv[1]);
@@ -1270,7 +1321,6 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t str
     // the tail: last layer + head (+ affine) behind the run's layers
     p.tail_q = 0;
     if (a->tail_q > 0) {
-        PWV_CHECK_ARG(a->precision == PWV_PREC_F16X3, "pwv_wavenet_stack_persist_f32: the tail (last layer + head inside the launch) exists for PWV_PREC_F16X3 only");
         for (int g = 0; g < a->G; ++g) {
             PWV_CHECK_ARG(a->tail_layer[g] && a->tail_head[g] && a->tail_out[g], "pwv_wavenet_stack_persist_f32: NULL tail buffer for net %d", g);
             p.tail_layer[g] = a->tail_layer[g];

@@ -698,13 +698,13 @@ def _same_structure(a, b) -> bool:
 
 def tail_fusable(prec: int) -> bool:
     """Does the persistent launch of this arithmetic run the net's last layer + head (+ affine) as its tail?"""
-    return bool(FUSE_TAIL and FUSE_HEAD and prec == _lib.PREC_F16X3)
+    return bool(FUSE_TAIL and FUSE_HEAD and prec in (_lib.PREC_F16X3, _lib.PREC_F32))      # (round 6: the exact-fp32 kernel has the tail too)
 
 
 def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, row_stride, cond_geom, n, t, s, prec, affine=None, tail=None):
     """Layers 0 .. L-2 as ONE persistent launch (layer 0 a launch of its own when it cannot rebuild the causal layer itself), with
     layer L-1 + the head behind it -- and, given `affine` = (x, out), the flow's affine out = x*s + b -- INSIDE that launch on the
-    split-fp16 path (FUSE_TAIL; otherwise one more launch for them); all nets of the flow in every launch, all on the current
+    split-fp16 and exact-fp32 paths (FUSE_TAIL; otherwise one more launch for them); all nets of the flow in every launch, all on the current
     stream.  `bufs[g]` holds THREE tile32 buffers: the persistent launch rotates through them (include/pwv_hip.h,
     pwv_persist_args.x_ring).  Returns True when the affine was evaluated by the launch."""
     G, L = len(nets), plans[0].n_layers

@@ -84,12 +84,14 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
     (1, 48000, 13, 2, 1, 0, 4),       # runs of 4 + 4 + 3 layers: the tail rides on the LAST run
     (1, 96, 5, 2, 1, 0, 32), (1, 40, 4, 2, 1, 0, 32),       # three units / two units in all (a ragged last unit)
     (2, 24000, 10, 1, 2, 0, 32), (1, 2400, 6, 1, 2, 2, 32)])        # one shared net with two outputs (BASELINE config 2): the affine in place
-def test_tail_and_affine_inside_the_launch_are_bit_identical_to_the_separate_launches(gpu, persist_knobs, n, t, L, G, Q, min_units, max_layers):
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_tail_and_affine_inside_the_launch_are_bit_identical_to_the_separate_launches(gpu, persist_knobs, n, t, L, G, Q, min_units, max_layers, precision):
     """Round 5: the net's last layer + head (modules.py:145-165) and the flow's affine (modules.py:59) run INSIDE the persistent
     launch (pwv_persist_args.tail_*: a flow is one launch instead of three).  Same operations in the same order as
     layer_f16x3_kernel<..., HEAD> and the affine kernel: the nets' outputs and the flow's output agree bit for bit with the
     separate launches (FUSE_TAIL off) and with the per-layer path -- three times in a row on one workspace (the pair counters
-    and progress words are left clean), eager."""
+    and progress words are left clean), eager.  Round 6: in the exact-fp32 arithmetic too (the operations of layer_f32_kernel<8, ..., HEAD>):
+    the path a range flag reruns on is one launch per flow as well."""
     import torch
     from pwv_amd.modules import WaveNet
     from pwv_amd.variables import VariableStore
@@ -103,25 +105,25 @@ def test_tail_and_affine_inside_the_launch_are_bit_identical_to_the_separate_lau
     g = torch.Generator().manual_seed(n * 13 + L)
     x = torch.randn((n, t, 1), generator=g).to(gpu)
     cond = engine.RepeatedCondition(torch.rand((n, t // 80 + 1, 80), generator=g).to(gpu), 80, 40, t)
-    engine.run_nets(nets, x, cond)  # creates the variables
+    engine.run_nets(nets, x, cond, precision=precision)  # creates the variables
     for name in list(store.vars):
         if store.vars[name].dim() == 1:
             store.vars[name].normal_(0, 0.1)
     store.version += 1
     engine.PERSIST = False
-    ref_outs = [o.clone() for o in engine.run_nets(nets, x, cond)]
-    ref_flow = engine.run_flow(nets, x, cond).clone()
+    ref_outs = [o.clone() for o in engine.run_nets(nets, x, cond, precision=precision)]
+    ref_flow = engine.run_flow(nets, x, cond, precision=precision).clone()
     engine.PERSIST, engine.PERSIST_MIN_UNITS, engine.PERSIST_MAX_LAYERS = True, min_units, max_layers
     engine.FUSE_TAIL = False
-    sep_flow = engine.run_flow(nets, x, cond).clone()
+    sep_flow = engine.run_flow(nets, x, cond, precision=precision).clone()
     torch.cuda.synchronize()
     assert engine.persist_status() == 0 and torch.equal(sep_flow, ref_flow)
     engine.FUSE_TAIL = True
     log = engine.EVENT_LOG = []
     try:
         for _ in range(3):
-            outs = engine.run_nets(nets, x, cond)
-            flow = engine.run_flow(nets, x, cond)
+            outs = engine.run_nets(nets, x, cond, precision=precision)
+            flow = engine.run_flow(nets, x, cond, precision=precision)
             torch.cuda.synchronize()
             assert engine.persist_status() == 0
             for a, b in zip(ref_outs, outs):

@@ -39,7 +39,8 @@ def bench(name):
 
 rows_md = []
 for name, label in (('c3', 'C3 default model 1 x 160000 (headline)'), ('c4', 'C4 share 8 x 64000'), ('c5', 'C5 transposed-conv 1 x 960000, f16x3'),
-                    ('c5_f16', 'C5, fp16 storage mode (reduced precision)')):
+                    ('c5_f16', 'C5, fp16 storage mode (reduced precision)'),
+                    ('skip', 'default model with `use_skip_connection: True` (modules.py:147), 1 x 160000 (round 6)')):
     b = bench(name)
     if not b:
         continue
@@ -49,7 +50,8 @@ for name, label in (('c3', 'C3 default model 1 x 160000 (headline)'), ('c4', 'C4
     if persist:
         pat = 'stack_persist_kernel'
     elif 'layer_f16x3' in roof['kernel']:
-        pat = 'layer_f16x3_kernel<false, true, false, false' if name.startswith('c5') else 'layer_f16x3_kernel<false, false, false, false'
+        pat = ('layer_f16x3_kernel<false, true, false, false' if name.startswith('c5') else
+               'layer_f16x3_kernel<true, false, false, false' if name == 'skip' else 'layer_f16x3_kernel<false, false, false, false')
     else:
         pat = 'layer_h16_kernel<true, false' if name.startswith('c5') else 'layer_h16_kernel<false, false'
     f, nf = sums(os.path.join(tmp, 'p4_%s_fetch.csv' % name), 'FETCH_SIZE', pat)
@@ -98,6 +100,12 @@ print('| config (one MI355X) | M samples/s | ms/step | whole model, frac of 8 TB
 print('|---|---|---|---|---|---|---|---|---|---|')
 for r in rows_md:
     print('| %s | %.1f | %.3f | %.3f | `%s` | %.3f | %.3f | %.2f | %.0f %% | %.0f / %.0f |' % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], 100 * r[8], r[9], r[10]))
+for name, label in (('in', "default model with `normalize_wavenet: 'in'` (modules.py:263-284), 1 x 16000: the composed path (round 6)"),
+                    ('16k', 'default model 1 x 16000, f16x3'), ('16k_f32', 'default model 1 x 16000, exact fp32 (the range guard\'s rerun path)'),
+                    ('c3_f32', 'C3, exact fp32'), ('c1', 'C1 one flow, 1 x 16000'), ('c2', 'C2 shared nets, 1 x 160000')):
+    b = bench(name)
+    if b:
+        print('\n%s: %.2f M samples/s, %.4f ms/step, whole model %.3f of 8 TB/s.' % (label, b['value'] / 1e6, b['ms_per_step'], b['model']['hbm_frac_of_8TBs']))
 pl = bench('c3_perlayer')
 if pl:
     print('\nC3 with the per-layer launches (PWV_PERSIST=0), same box: %.1f M samples/s, %.3f ms/step, whole model %.3f of 8 TB/s.'
