@@ -158,9 +158,9 @@ def cpu_baseline_measure(case_cfg, target_s, chunk=4000, mode='process', per=4):
 
     rates, pers, prev = {}, {}, None
     for k in sweep:
-        # `per` chunks per worker -- fewer only where the point would run beyond ~20 s at the rate of the point before it (the
+        # `per` chunks per worker -- fewer only where the point would run beyond ~12 s at the rate of the point before it (the
         # physical-core point of a 128-core host past the memory-bound knee: 2 M samples at a third of the best rate)
-        pers[k] = per if prev is None else int(max(1, min(per, 20.0 * prev // (k * chunk))))
+        pers[k] = per if prev is None else int(max(1, min(per, 12.0 * prev // (k * chunk))))
         rates[k] = prev = point(k, per_k=pers[k])[0]
     best = max(rates, key=lambda k: rates[k])
     first_pass = rates[best]

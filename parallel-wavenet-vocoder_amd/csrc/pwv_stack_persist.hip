@@ -959,6 +959,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) nf[i] = frag(lds, kHS, i, 8, 0, lane);
                             });
+                        asm volatile("" ::: "memory");      // (the bias loads below stay behind GEMM1: hoisted to the top of the unit they are 64 + 64 registers too many)
                         f32x16 accs[4];
 #pragma unroll
                         for (int it = 0; it < 4; ++it)
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
 #pragma unroll
                             for (int i = 0; i < 4; ++i) nf[i] = frag(lds, kH1, i, 16, 0, lane);
                         });
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -1062,11 +1064,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     }
                     load_tail(next, txb, txc);      // the next unit's rows: in flight under the postprocess2 dot
                     float outv[kMaxQ] = {0.f, 0.f, 0.f, 0.f};
-                    int out_idx = row * Q;      // (made here, behind the GEMMs, and opaque: as a loop-carried induction variable it is one register too many
-                    asm volatile("" : "+v"(out_idx));      //  for the exact-fp32 instantiation, which then spills it)
+                    // (the addresses of the postprocess2 dot are made here, behind the GEMMs, from opaque copies: hoisted out of the unit loop as
+                    // loop-invariant per-lane pointers they are the registers the exact-fp32 instantiation has to spill)
+                    int out_idx = row * Q, hq = h * Q;
+                    asm volatile("" : "+v"(out_idx), "+v"(hq));
                     for (int q = 0; q < Q; ++q) {
                         float part = 0.f;
-                        const float* w2 = hb + kHW2 + (h * Q + q) * 64;
+                        const float* w2 = hb + kHW2 + (hq + q) * 64;
 #pragma unroll
                         for (int i4 = 0; i4 < 16; ++i4) {
                             const f32x4 wv = *reinterpret_cast<const f32x4*>(w2 + 4 * i4);
