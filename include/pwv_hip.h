@@ -364,7 +364,7 @@ int pwv_wavenet_stack_f32(const pwv_stack_args* args, pwv_stream_t const* stream
  * Normalisers (modules.normalize, modules.py:263-284) and the elementwise ops of the un-fused WaveNet path.
  *   pwv_instance_norm_f32   method 'in' (modules.py:274-284): per (utterance, channel) mean / biased variance over the
  *                           TIME axis, y = gamma (x - mean) / sqrt(var + eps) + beta, eps = 1e-8 in the reference;
- *                           x, y [N, T, C] channels-last; gamma / beta [C] or NULL; two launches (fp64 partial sums per
+ *                           x, y [N, T, C] channels-last; gamma / beta [C] or NULL; three launches (fp64 partial sums per
  *                           time chunk, no atomics: bitwise repeatable), workspace from pwv_instance_norm_workspace_bytes.
  *   pwv_channel_affine_f32  y = act(x * scale[c] + bias[c]) -- method 'bn' at inference (modules.py:266: scale =
  *                           gamma / sqrt(moving_variance + 1e-3), bias = beta - moving_mean * scale) where no GEMM follows

@@ -90,26 +90,48 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const double* __restrict__ partial,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int T, int C,
-                                                       int chunks, int rows_per_block, float eps) {
+// Pass 1b (round 6): ONE block per utterance reduces the partials to the per-channel scale / shift (fp64, fixed order: bitwise
+// repeatable) -- every block of the apply pass used to repeat this reduction serially over up to 512 partials, which was 78 us of its
+// 80 at 16000 samples (profiles/r06_z_in_kernel_stats.md of the build before).  256 threads = 256 / cl k-lanes per channel.
+__global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restrict__ partial, float* __restrict__ ab, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int T, int C, int chunks, float eps) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.x;
+    const int cl = C < 256 ? C : 256;
+    const int kl = 256 / cl > 0 ? 256 / cl : 1;
+    const int tc = threadIdx.x % cl, tk = threadIdx.x / cl;
+    for (int c0 = 0; c0 < C; c0 += cl) {
+        const int c = c0 + tc;
+        double s = 0.0, q = 0.0;
+        if (c < C && tk < kl)
+            for (int k = tk; k < chunks; k += kl) {
+                const double* src = partial + (((size_t)n * chunks + k) * C + c) * 2;
+                s += src[0];
+                q += src[1];
+            }
+        red[0][threadIdx.x] = s;
+        red[1][threadIdx.x] = q;
+        __syncthreads();
+        if (tk == 0 && c < C) {
+            for (int k = 1; k < kl; ++k) { s += red[0][k * cl + tc]; q += red[1][k * cl + tc]; }
+            const double mean = s / T;
+            double var = q / T - mean * mean;               // tf.nn.moments: the biased variance
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / sqrt(var + (double)eps);     // (variance + epsilon) ** .5, modules.py:282
+            const double gm = gamma ? (double)gamma[c] : 1.0;
+            ab[(size_t)n * 2 * C + c] = (float)(gm * inv);
+            ab[(size_t)n * 2 * C + C + c] = (float)((beta ? (double)beta[c] : 0.0) - gm * inv * mean);
+        }
+        __syncthreads();
+    }
+}
+
+// Pass 2: y = x * scale[c] + shift[c]
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ ab_all,
+                                                       int T, int C, int rows_per_block) {
     extern __shared__ float ab[];      // [C] scale, [C] shift
     const int n = blockIdx.y;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            const double* src = partial + (((size_t)n * chunks + k) * C + c) * 2;
-            s += src[0];
-            q += src[1];
-        }
-        const double mean = s / T;
-        double var = q / T - mean * mean;               // tf.nn.moments: the biased variance
-        if (var < 0.0) var = 0.0;
-        const double inv = 1.0 / sqrt(var + (double)eps);     // (variance + epsilon) ** .5, modules.py:282
-        const double gm = gamma ? (double)gamma[c] : 1.0;
-        ab[c] = (float)(gm * inv);
-        ab[C + c] = (float)((beta ? (double)beta[c] : 0.0) - gm * inv * mean);
-    }
+    for (int c = threadIdx.x; c < 2 * C; c += 256) ab[c] = ab_all[(size_t)n * 2 * C + c];
     __syncthreads();
     const int t0 = blockIdx.x * rows_per_block;
     const int t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
@@ -260,7 +282,7 @@ size_t pwv_instance_norm_workspace_bytes(int N, int T, int C) {
     // utterance to 8 blocks -- 165 us per call on a chip that reads the tensor in 2; profiles/r06_configs.md, bench/in)
     int chunks = (T + 63) / 64;
     if (chunks > kInMaxChunks) chunks = kInMaxChunks;
-    return (size_t)N * chunks * C * 2 * sizeof(double);
+    return (size_t)N * chunks * C * 2 * sizeof(double) + (size_t)N * 2 * C * sizeof(float);      // partial sums, then scale | shift per (n, c)
 }
 
 int pwv_instance_norm_f32(const float* x, float* y, int N, int T, int C, const float* gamma, const float* beta, float eps,
@@ -276,9 +298,11 @@ int pwv_instance_norm_f32(const float* x, float* y, int N, int T, int C, const f
     chunks = (T + chunk_len - 1) / chunk_len;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(in_stats_kernel, dim3(chunks, N), dim3(256), 0, s, x, (double*)workspace, T, C, chunk_len, chunks);
-    const int rows_per_block = 256;
+    float* ab = (float*)((double*)workspace + (size_t)N * chunks * C * 2);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)workspace, ab, gamma, beta, T, C, chunks, eps);
+    const int rows_per_block = 64;
     hipLaunchKernelGGL(in_apply_kernel, dim3((T + rows_per_block - 1) / rows_per_block, N), dim3(256), 2 * C * sizeof(float), s, x, y,
-                       (const double*)workspace, gamma, beta, T, C, chunks, rows_per_block, eps);
+                       (const float*)ab, T, C, rows_per_block);
     PWV_CHECK_HIP(hipGetLastError());
     return PWV_OK;
 }

@@ -95,7 +95,7 @@ for name, label in (('c3', 'C3 default model 1 x 160000 (headline)'), ('c4', 'C4
     rows_md.append((label, b['value'] / 1e6, b['ms_per_step'], b['model']['hbm_frac_of_8TBs'], roof['kernel'].split(' (')[0], roof['frac'],
                     tj.get('frac_rocprof', float('nan')), traffic / alg, busy / (act / 8.0 * simds) if act else float('nan'),
                     valu / units, mfma / units))
-print('# per-configuration table (tools/profile_round4.sh, %s): bench line + rocprofv3 stats + PMC passes of the same build on one box\n' % tag)
+print('# per-configuration table (tools/profile_round4.sh / profile_round6.sh, %s): bench line + rocprofv3 stats + PMC passes of the same build on one box\n' % tag)
 print('| config (one MI355X) | M samples/s | ms/step | whole model, frac of 8 TB/s | dominant kernel | its frac of 8 TB/s, HIP events (bench `roofline.frac`) | same from the rocprofv3 --stats average | HBM traffic / algorithmic bytes | matrix pipe busy | VALU / MFMA instructions per 32-row unit |')
 print('|---|---|---|---|---|---|---|---|---|---|')
 for r in rows_md:
