@@ -71,6 +71,55 @@ __device__ __forceinline__ void gemm16(const f16x8* A, int lane, f32x16 (&acc)[N
     }
 }
 
+// The same over the k-steps [S0, S1) of a GEMM whose fragments are NS k-steps apart (round 6: the short-input instantiation of the persistent
+// kernel runs the x[t] half of BOTH row-tile pairs before the x[t-d] half of either; per accumulator the order of the k-steps is unchanged)
+template <int NS, int S0, int S1, int NIT, int IT0, int ITSTEP, int NITTOT, int NACC, typename BH, typename BL, typename EF, typename TF>
+__device__ __forceinline__ void gemm16r(const f16x8* A, int lane, f32x16 (&acc)[NACC], f16x8 (&ah)[4], f16x8 (&al)[4],
+                                        BH&& bh, BL&& bl, EF&& extra, TF&& tail) {
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        f16x8 nh[4] = {ah[0], ah[1], ah[2], ah[3]};
+        f16x8 nl[4] = {al[0], al[1], al[2], al[3]};
+        if (s + 1 < S1) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                nh[i] = frag16<NS, NITTOT>(A, 0, IT0 + i * ITSTEP, s + 1, lane);
+                nl[i] = frag16<NS, NITTOT>(A, 1, IT0 + i * ITSTEP, s + 1, lane);
+            }
+        } else {
+            tail(nh, nl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 b_h = bh(s);
+        const f16x8 b_l = bl(s);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b_h, acc[IT0 + i * ITSTEP], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b_l, acc[IT0 + i * ITSTEP], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            acc[IT0 + i * ITSTEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b_h, acc[IT0 + i * ITSTEP], 0, 0, 0);
+        extra(s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = nh[i];
+            al[i] = nl[i];
+        }
+    }
+}
+
+template <int NS, int S, int NIT, int IT0, int ITSTEP, int NITTOT>
+__device__ __forceinline__ void frags_at(const f16x8* A, int lane, f16x8 (&h)[4], f16x8 (&l)[4]) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        h[i] = frag16<NS, NITTOT>(A, 0, IT0 + i * ITSTEP, S, lane);
+        l[i] = frag16<NS, NITTOT>(A, 1, IT0 + i * ITSTEP, S, lane);
+    }
+}
+
 template <int NS, int NIT, int IT0, int ITSTEP, int NITTOT>
 __device__ __forceinline__ void first_frags(const f16x8* A, int lane, f16x8 (&h)[4], f16x8 (&l)[4]) {
 #pragma unroll

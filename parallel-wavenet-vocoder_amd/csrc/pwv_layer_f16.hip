@@ -212,20 +212,37 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
                 }
             }
         }
-        f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
+        // B operands: bh[0..3] = x[t-d], bh[4..7] = x[t].  The packed K order is x[t] FIRST (k-steps 0..3), then x[t-d] (round 6): a unit's own
+        // rows are what a stationary wave of the persistent kernel still holds in registers, the look-back row is what it waits for -- every
+        // kernel accumulates in that order, so all paths stay bit-identical.  x[t-d] is split under the first four MFMA groups of pair 0.
+        f16x8 bh[8], bl[8];
         float xc[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) xc[i] = rxc[i];
+        // (with a per-sample condition its GEMM comes first: x[t-d] is split up front, as before, and x[t] under the condition GEMM's first
+        //  four groups -- any more operands in front of that GEMM are spilled registers)
+        auto split_xc = [&](int s) {
+            if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
+            if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
+            if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
+            if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+        };
+        auto split_xb = [&](int s) {
+            if (s == 0) { split8<0>(rxb, bh[0], bl[0]); asm volatile("" : "+v"(bh[0]), "+v"(bl[0])); }
+            if (s == 1) { split8<8>(rxb, bh[1], bl[1]); asm volatile("" : "+v"(bh[1]), "+v"(bl[1])); }
+            if (s == 2) { split8<16>(rxb, bh[2], bl[2]); asm volatile("" : "+v"(bh[2]), "+v"(bl[2])); }
+            if (s == 3) { split8<24>(rxb, bh[3], bl[3]); asm volatile("" : "+v"(bh[3]), "+v"(bl[3])); }
+        };
         if constexpr (!FOLD) {
-            split8<0>(rxb, bh[0], bl[0]);
-            split8<8>(rxb, bh[1], bl[1]);
-            split8<16>(rxb, bh[2], bl[2]);
-            split8<24>(rxb, bh[3], bl[3]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if constexpr (COND) split_xb(s);
+                else split_xc(s);
+            }
         }
-        // x[t] (k-steps 4..7) is split under the first four MFMA groups of pair 0
 
-        auto bxh = [&](int s) -> f16x8 { return bh[s]; };
-        auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+        auto bxh = [&](int s) -> f16x8 { return bh[s ^ 4]; };
+        auto bxl = [&](int s) -> f16x8 { return bl[s ^ 4]; };
         auto bch = [&](int s) -> f16x8 { return ch[COND ? s : 0]; };
         auto bcl = [&](int s) -> f16x8 { return cl[COND ? s : 0]; };
 
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]) ----------------------------------------
         if constexpr (COND) {
             first_frags<5, 2, 0, 2, 4>(AC, lane, ah, al);
-            gemm16<5, 2, 0, 2, 4>(AC, lane, acc, ah, al, bch, bcl, no_extra,
+            gemm16<5, 2, 0, 2, 4>(AC, lane, acc, ah, al, bch, bcl, split_xc,
                                   [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 0, 2, 4>(A1, lane, nh, nl); });
         } else {
             first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
@@ -272,10 +289,7 @@ __global__ __launch_bounds__(512) void layer_f16x3_kernel(const LayerParams p) {
         gemm16<8, 2, 0, 2, 4>(
             A1, lane, acc, ah, al, bxh, bxl,
             [&](int s) {
-                if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
-                if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
-                if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
-                if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+                if constexpr (!COND) split_xb(s);
             },
             [&](f16x8(&nh)[4], f16x8(&nl)[4]) {
                 if constexpr (COND) first_frags<5, 2, 1, 2, 4>(AC, lane, nh, nl);
@@ -644,7 +658,7 @@ __global__ void pack_layer_f16_kernel(const float* filter, const float* gate, co
     const int base = u;
     if (u < kA1Size / 4) {
         PWV_DECODE(u, 4, 8)
-        const int tap = s >> 2, oc = 32 * it + i;
+        const int tap = 1 - (s >> 2), oc = 32 * it + i;      // k-steps 0..3 = x[t] (tap 1), 4..7 = x[t-d] (tap 0): see the B operands
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int cin = 16 * (s & 3) + 8 * (q >> 2) + 4 * h + (q & 3);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(HEAD ? 512 : 256, HEAD ? 1 : PWV_H16_MINWAVES) void
 #pragma unroll
             for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F0[it * 64 + lane], fold_b, acc[it], 0, 0, 0);
         } else {
-            gemm_h<8, 4>(&lds[kH_A1], lane, acc, [&](int s) -> f16x8 { return b[s]; });
+            gemm_h<8, 4>(&lds[kH_A1], lane, acc, [&](int s) -> f16x8 { return b[s ^ 4]; });      // (packed K order: x[t] first, see pack_layer_f16_kernel)
         }
 
         float o[32];

@@ -52,8 +52,12 @@ constexpr int kCtlF = kBiasF + 128;            // control ints: [0] task counter
 constexpr int kCtlInts = 40;
 constexpr int kLdsFloats = 40960;              // all 160 KB of the CU
 constexpr int kCfF = kCtlF + kCtlInts;       // causal filter [2][64] (a run that starts with the net's layer 0, see x_first)
-constexpr int kDoneB = (kCfF + 128) * 4;                   // byte offset of the per-unit "layers completed" bytes
-constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 864 units per workgroup
+constexpr int kLeftN = 32;                                 // unit mode (short inputs): "layers completed" bytes of the 32 units LEFT of the range, as last seen
+constexpr int kLeftB = (kCfF + 128) * 4;                   // ... in front of the own units' bytes, so one linear address serves both
+constexpr int kDoneB = kLeftB + kLeftN;                    // byte offset of the per-unit "layers completed" bytes
+constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 832 units per workgroup
+constexpr int kUnitModeMaxPerWg = 4;                       // unit mode up to this many units per workgroup and layer
+constexpr int kUnitStride = 32;                            // ints between two units' words (own 128-byte lines: a poll asks for exactly the unit it waits for)
 constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
 constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
 constexpr int kMaxPLayers = 32;
@@ -67,6 +71,8 @@ struct PersistParams {
     const float* packed[PWV_MAX_NETS];     // packed layers of this launch, `packed_stride` floats apart
     const float* proj[PWV_MAX_NETS];       // P rows; this launch's first layer at column 0, layer j at 128 j
     int* prog;                             // [G][nwg] progress words, kProgStride ints apart, zeroed per launch
+    int* uprog;                            // unit mode: [G][units] "layers completed" per UNIT (the left neighbours' top units are what a range's bottom units wait for)
+    int unit_mode;
     int* abort;                            // one word behind them: != 0 once any wave of the launch has given up
     int* exited;                           // ... and one more: workgroups that have finished; the last one zeroes all of these words
     int active_wgs;                        // workgroups that own units (the others return at once)
@@ -84,6 +90,7 @@ struct PersistParams {
     float x_limit;                         // range guard of the split-fp16 arithmetic on x_first (include/pwv_hip.h)
     int* range_flag;
     long long* trace;                      // -DPWV_PTRACE builds: per-wave cycle accounting (tools/persist_trace.py)
+    long long* trace_ev;                   // -DPWV_PTRACE builds: per-wave event timeline, [wave][64][4] = {s_memrealtime, code, layer, unit | bits << 32}
     // TAIL (tail_q > 0; both arithmetics since round 6): behind the run's layers every workgroup runs the net's LAST layer with the post-processing
     // head behind it on its own units (layer_f16x3_kernel's HEAD variant, the same operations) -- and, with `pair`, the IAF affine
     const float* tail_layer[PWV_MAX_NETS]; // the last layer's packed weights (its filter|gate fragments are used)
@@ -106,6 +113,10 @@ struct PersistParams {
 #define PT_ADD(k, v) pt_acc[k] += (v)
 #define PT_MARK() do { __builtin_amdgcn_sched_barrier(0); pt_p = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PT_PHASE(k) do { __builtin_amdgcn_sched_barrier(0); const long long pt_n = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_n - pt_p; pt_p = pt_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+// event timeline (round 6, tools/persist_timeline.py): 1 unit computed, 2 stores issued, 3 own stores acknowledged (in front of a wait; 13 in front of a WAR wait), 4 dependencies
+// satisfied (12: the WAR ones; bits << 32: what was missing at the first look), 5 rows arrived + look-back split, 6 top drained, 7 workgroup progress word published, 8 tail entered
+#define PT_EV(code, jj, uu) do { if (p.trace_ev && pt_nev < 64) { if (lane == 0) { long long* e_ = p.trace_ev + (((size_t)blockIdx.x * 8 + wave) * 64 + pt_nev) * 4; \
+    e_[0] = __builtin_amdgcn_s_memrealtime(); e_[1] = (code); e_[2] = (jj); e_[3] = (long long)(uu); } ++pt_nev; } } while (0)
 #else
 #define PT_DECL
 #define PT_BEGIN() do {} while (0)
@@ -113,6 +124,7 @@ struct PersistParams {
 #define PT_ADD(k, v) do {} while (0)
 #define PT_MARK() do {} while (0)
 #define PT_PHASE(k) do {} while (0)
+#define PT_EV(code, jj, uu) do {} while (0)
 #endif
 
 // dependency bits of a task: [0] own x[t] rows, [1] [2] x[t-d] rows, [3] this layer's weights resident (RAW side);
@@ -176,7 +188,10 @@ __device__ __forceinline__ void gemm_groups_dense(FR&& fr, f32x16 (&acc)[2], f32
     }
 }
 
-template <bool F32>
+// SHORT (round 6): the instantiation for short inputs (at most kUnitModeMaxPerWg units per workgroup and layer: progress words per unit, stationary
+// units, a loader wave) -- a template parameter, not a run-time mode: as run-time branches in the general task loop the additions cost the long-input
+// launch 2.7 % of its step (SGPR spills reloaded per unit, profiles/r06_ab_experiments.md r06_r)
+template <bool F32, bool SHORT>
 __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int tid = threadIdx.x;
@@ -201,6 +216,11 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     const int n = u_end - u_begin;
     if (n <= 0) return;      // owns nothing; nobody waits for it (the neighbour sets stop at the last owning workgroup)
     const int L = p.n_layers;
+    constexpr bool stat = SHORT;                        // stationary units (below, at the task loop): n <= kUnitModeMaxPerWg <= 8 units, one per wave
+    constexpr bool loader_mode = SHORT;                 // ... leave idle waves (n <= kUnitModeMaxPerWg = 4 < 8): wave 7 is the workgroup's loader
+#ifdef PWV_PTRACE
+    int pt_nev = 0;
+#endif
 
     typedef __attribute__((address_space(3))) int* lds_ints_t;
     const lds_ints_t ctl = (lds_ints_t)(lds + kCtlF);
@@ -208,6 +228,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     typedef __attribute__((address_space(3))) volatile unsigned char* lds_bytes_t;
     const lds_bytes_t lb = (lds_bytes_t)lds;
     int* prog_n = p.prog + (size_t)net * p.nwg * kProgStride;
+    int* uprog_n = p.uprog + (size_t)net * p.units * kUnitStride;
     const float* const proj_n = p.proj[net];
     const float* const packed_n = p.packed[net];
     // the per-layer dilations live in one VGPR (lane j holds entry j), read with v_readlane: a dynamically indexed kernel
@@ -297,6 +318,39 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         else load_b(has_prev);
     };
 
+    // the unit's own rows alone (stationary units: once, in front of the task loop)
+    auto load_xc = [&](int j, int unit, float (&xc)[32]) {
+        int row, rc, nn, t;
+        bool valid;
+        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+        const int so = in_soff(j);
+        const int oc = toff(rc);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, oc + g * 1024, so, 16));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xc[4 * g + e] = v[e];
+        }
+    };
+    // the look-back row alone (stationary units, layers >= 1)
+    auto load_xb = [&](int j, int unit, float (&xb)[32]) {
+        int row, rc, nn, t;
+        bool valid;
+        unit_rows(unit, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+        const int d = dil_of(j);
+        const bool has_prev = t >= d;
+        const int so = in_soff(j);
+        const int ob = toff(has_prev ? rc - d : rc);
+        // (no select here: rows left of the utterance start are zeroed where the row is USED -- a select, or two paths that the register
+        //  allocator joins with copies, behind these loads is a wait for them right here)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rs, ob + g * 1024, so, 16));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[4 * g + e] = v[e];
+        }
+    };
+
     // ---- dependencies: lane k < 6 of a wave looks at ONE byte of LDS ------------------------------------------------------
     //   k = 0: own x[t] rows, 1 / 2: the x[t-d] rows (units u - ceil(d/32), u - floor(d/32)), 3: this layer's weights resident,
     //   4 / 5: the readers of the ring slot the task overwrites (layer j-2's tasks of the units u + floor(d'/32), u + ceil(d'/32)).
@@ -312,7 +366,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     auto dep_addr = [&](int j, int u) -> int {
         const int v = u + (int)(short)vpack;
         int a = kDoneB - u_begin + v;
-        a = v < u_begin ? kSeenLB : a;
+        a = (v < u_begin && !SHORT) ? kSeenLB : a;      // (unit mode: the byte of that very unit, kLeftN bytes in front of the own ones)
         a = v >= u_end ? kSeenRB : a;
         a = (v < 0 || v >= p.units) ? kTrueB : a;
         a = lane == 3 ? kWreadyB + (j & 1) : a;
@@ -321,12 +375,48 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     // bit k set: dependency k is NOT yet satisfied
     auto eval = [&](int addr) -> unsigned { return (unsigned)__ballot((int)lb[addr] < (vpack >> 16)); };
     // neighbours' progress words -> the cached "seen" byte of that side (only ever raised to a value that was observed)
+    auto wave_min = [&](int v) -> int {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
+        return v;
+    };
+    // (round 6: the byte takes the value that was OBSERVED, not just `need` -- a neighbour is usually a layer further on than what is
+    //  asked for, and a poll is a 1.5 us round trip to the fabric for a word another CU wrote through)
     auto poll_side = [&](int side, int need) {
         const int w0 = side ? w + 1 : (w - p.reach_wgs > 0 ? w - p.reach_wgs : 0);
         const int cnt = side ? (w + p.reach_wgs < p.last_wg ? p.reach_wgs : p.last_wg - w) : w - w0;
-        int v = 1 << 20;
-        if (lane < cnt) v = __hip_atomic_load(prog_n + (size_t)(w0 + lane) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot(v < need) == 0) lb[side ? kSeenRB : kSeenLB] = (unsigned char)need;
+        int v = 255;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));      // (address made here, not hoisted out of the task loop into a spilled register pair)
+        if (lo < cnt) v = __hip_atomic_load(prog_n + (size_t)(w0 + lo) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SHORT) {
+            const int m = wave_min(v);
+            if (m >= need) lb[side ? kSeenRB : kSeenLB] = (unsigned char)m;
+        } else {
+            if (__ballot(v < need) == 0) lb[side ? kSeenRB : kSeenLB] = (unsigned char)need;
+        }
+    };
+    // unit mode: lanes 1 / 2 ask for exactly the unit they wait for (own 128-byte line each), lanes 32.. for the right neighbours'
+    // workgroup words in the same instruction (the WAR side's byte is refreshed on the way, so the top unit's stores rarely have to poll)
+    auto poll_units = [&](int addr, int jw) {
+        const int cnt_r = w + p.reach_wgs < p.last_wg ? p.reach_wgs : p.last_wg - w;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));      // (the addresses are made HERE: hoisted out of the task loop as loop-invariant per-lane pointers they are spilled registers)
+        const bool left = (lo == 1 || lo == 2) && addr >= kLeftB && addr < kDoneB;
+        int v = 255;
+        if (left) {
+            v = __hip_atomic_load(uprog_n + (size_t)(u_begin - kLeftN + addr - kLeftB) * kUnitStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lo >= 32 && lo - 32 < cnt_r) {
+            v = __hip_atomic_load(prog_n + (size_t)(w + 1 + lo - 32) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        v = v > 255 ? 255 : v;
+        if (left) lb[addr] = (unsigned char)v;
+        // (the right neighbours are normally at layer jw or one further: two ballots instead of a reduction)
+        if (cnt_r > 0) {
+            const bool r = lo >= 32;
+            if (__ballot(r && v < jw + 1) == 0) lb[kSeenRB] = (unsigned char)(jw + 1);
+            else if (__ballot(r && v < jw) == 0 && (int)lb[kSeenRB] < jw) lb[kSeenRB] = (unsigned char)jw;
+        }
     };
 
     // what this wave owes the others: the unit it has just stored and a weight refill it has issued (true at a vmcnt(0))
@@ -335,7 +425,11 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     int left_upto = 0;                   // layers [0, left_upto) this wave has counted itself out of
     bool dead = false;
     auto publish = [&]() {               // (all lanes store the same byte: no exec juggling)
-        if (prev_addr >= 0) { lb[prev_addr] = (unsigned char)(prev_j + 1); prev_addr = -1; }
+        if (prev_addr >= 0) {
+            lb[prev_addr] = (unsigned char)(prev_j + 1);
+            if (SHORT && lane == 0) __hip_atomic_store(uprog_n + (size_t)(prev_addr - kDoneB + u_begin) * kUnitStride, prev_j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev_addr = -1;
+        }
         if (dma_pending >= 0) { lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
     };
     auto flush_owed = [&]() {
@@ -350,8 +444,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             int old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(&ctl[8 + jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             old = __builtin_amdgcn_readfirstlane(old);
-            if (old == 7) {
+            if (old == 7 && !loader_mode) {
                 if (lane == 0) __hip_atomic_store(prog_n + (size_t)w * kProgStride, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                PT_EV(7, jj, -1);
                 if (jj + 2 < L) {
                     if (dma_pending >= 0) flush_owed();       // (last twice in a row: announce the earlier refill first)
                     fill_slot(jj & 1, jj + 2, 0, 1);
@@ -366,26 +461,41 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         // never spin while holding unpublished work -- and "work" includes leaving the layers this wave has moved past: with few
         // units per workgroup a wave's next task can be two layers on, and the weights it then waits for are refilled by the
         // LAST wave to leave the layer it has just finished
-        flush_owed();
+        if (!SHORT || prev_addr >= 0 || dma_pending >= 0) {
+            flush_owed();
+            PT_EV(mask == kWarMask ? 13 : 3, j, u);
+        }
         leave_layers(j);
         if (dma_pending >= 0) flush_owed();
         if (lv != j) layer_vectors(j);
         const int addr = dep_addr(j, u);
         bool ok = false;
         const long long t0 = __builtin_amdgcn_s_memrealtime();
+#ifdef PWV_PTRACE
+        unsigned pt_bad0 = 0, pt_badl = 0;
+        int pt_polls = 0;
+#endif
         for (int k = 0; !ok; ++k) {
             const unsigned bad = eval(addr) & mask;
+#ifdef PWV_PTRACE
+            if (k == 0) pt_bad0 = bad;
+            if (bad) pt_badl = bad;
+            pt_polls = k;
+#endif
             if (!bad) { ok = true; break; }
             // somebody has given up (this workgroup: LDS word; any workgroup of the launch: the word behind the progress words,
             // looked at every 64th poll), or this wait has lasted 20 ms: give up too.  (readfirstlane: the loop stays wave-uniform)
             if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1])) break;
             if ((k & 63) == 63 && (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
                                    __builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks)) break;
-            if ((bad & 0x6u) && __ballot(addr == kSeenLB && (lane == 1 || lane == 2))) poll_side(0, j);
+            if constexpr (SHORT) {
+                if ((bad & 0x6u) && __ballot((lane == 1 || lane == 2) && addr < kDoneB && addr >= kLeftB)) poll_units(addr, j);
+            } else if ((bad & 0x6u) && __ballot(addr == kSeenLB && (lane == 1 || lane == 2))) poll_side(0, j);
             if ((bad & 0x30u) && __ballot(addr == kSeenRB && (lane == 4 || lane == 5))) poll_side(1, j - 1);
             __builtin_amdgcn_s_sleep(4);
         }
         if (lv != j) layer_vectors(lv);
+        PT_EV(mask == kWarMask ? 12 : 4, j, (long long)u | ((long long)pt_bad0 << 32) | ((long long)pt_badl << 40) | ((long long)pt_polls << 48));
         if (ok) return;
         // (every lane stores the same words: a lane-0 branch here makes the compiler treat `dead`, and with it the whole
         // task loop, as divergent -- scalar bookkeeping in VGPRs, a waterfall loop around every buffer access)
@@ -406,9 +516,17 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         while (j < L && i >= (j + 1) * n) ++j;      // (normally zero or one step: keep it a three-instruction scalar loop)
         return j < L ? u_end - 1 - (i - j * n) : -1;
     };
+    // STATIONARY units (round 6; unit mode with at most one unit per wave): wave k owns unit u_end - 1 - k in EVERY layer, the other waves
+    // have no tasks.  The unit's own rows x[t] then never travel: they are the accumulators the wave has just stored, and what it has to
+    // fetch between two layers is the look-back row alone -- half the bytes in the CU's memory queue at the one moment a short layer waits
+    // for (a CU loads freshly written rows at ~ 30 GB/s, latency-bound: 2.2 us for its four units' 64 KB; profiles/r06_short_timeline.md).
     int j = 0;
-    int u = locate(__builtin_amdgcn_readfirstlane(claim()), j);
-    int claim_v = claim();                 // the task after that
+    int u = stat ? (wave < n ? u_end - 1 - wave : -1) : locate(__builtin_amdgcn_readfirstlane(claim()), j);
+    int claim_v = stat ? 0 : claim();      // the task after that
+    auto next_task = [&](int jc, int uc, int& jn) -> int {
+        if (stat) { jn = jc + 1; return jn < L ? uc : -1; }
+        return locate(__builtin_amdgcn_readfirstlane(claim_v), jn);
+    };
     float rxb[32], rxc[32];
     bool war_ok = true;                    // (of the task in hand; its RAW side is satisfied when it starts)
     PT_DECL
@@ -417,6 +535,37 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     const long long pt_start_rt = __builtin_amdgcn_s_memrealtime();
     pt_acc[7] = pt_start;
 #endif
+    // ---- the loader (stationary units with an idle wave): it waits for the n active waves to have left layer jj, publishes the workgroup's
+    // progress word and refills the LDS slot with layer jj + 2.  Left to the last wave to leave, as in the general scheme, the 80 KB of LDS-DMA
+    // sit in THAT wave's memory queue in front of its next look-back row: 3 us on the top unit of every layer (r06_m timeline).
+    if (loader_mode && wave == 7) {
+        __builtin_amdgcn_s_setprio(0);      // (it shares its SIMD with an active wave)
+        bool gone = false;
+        for (int jj = 0; jj < L && !gone; ++jj) {
+            const long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (int k = 0;; ++k) {
+                if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[8 + jj]) >= n) break;
+                if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1])) { gone = true; break; }
+                if ((k & 63) == 63 && (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
+                                       __builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks)) {
+                    __hip_atomic_store(p.status, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(__attribute__((address_space(3))) volatile int*)&ctl[1] = 1;
+                    gone = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (gone) break;
+            if (lane == 0) __hip_atomic_store(prog_n + (size_t)w * kProgStride, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PT_EV(7, jj, -1);
+            if (jj + 2 < L) {
+                fill_slot(jj & 1, jj + 2, 0, 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lb[kWreadyB + (jj & 1)] = (unsigned char)(jj + 2);
+            }
+        }
+    }
     // ---- layer 0 in its folded form (pwv_persist_args.first_fold), a loop of its own in front of the general one.
     // h[t] = x[t-1] w0 + x[t] w1 (modules.py:179-180) makes filter|gate(h[t-d], h[t]) a [4 -> 128] map of the scalars
     // x[t-d-1], x[t-d], x[t-1], x[t]: ONE split-fp16 MFMA k-step (4 of its 16 k values used) instead of eight -- two fp32
@@ -475,11 +624,11 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     }
             }
             int j2 = 0;
-            const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);
+            const int u2 = next_task(0, u, j2);
             // drain (the loads above, the previous unit's stores), publish that unit, claim the task after the next
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             publish();
-            if (u2 >= 0) claim_v = claim();
+            if (u2 >= 0 && !stat) claim_v = claim();
             if (p.range_flag && !(fabsf(x0) <= p.x_limit)) __hip_atomic_store(p.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if constexpr (F32) {
                 const float b0 = h ? xd0 : xd1, b1 = h ? x0 : x1v;      // k = 0, 1 | k = 2, 3
@@ -563,6 +712,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     }
                 }
             }
+            PT_EV(2, 0, u);
             prev_addr = kDoneB + (u - u_begin);
             prev_j = 0;
             j = j2;
@@ -574,19 +724,35 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         flush_owed();
         leave_layers(j);
         layer_vectors(j);
-        const unsigned bad = eval(dep_addr(j, u));
-        if (bad & kRawMask) wait_deps(j, u, kRawMask, j, 4);
-        war_ok = (bad & kWarMask) == 0;
-        if (!dead) load_x(j, u, rxb, rxc);
+        if constexpr (SHORT) {
+            // the unit's own rows: this wave's own layer-0 output (stationary units; complete: the drain above) or the run's input
+            load_xc(j, u, rxc);
+        } else {
+            const unsigned bad = eval(dep_addr(j, u));
+            if (bad & kRawMask) wait_deps(j, u, kRawMask, j, 4);
+            war_ok = (bad & kWarMask) == 0;
+            if (!dead) load_x(j, u, rxb, rxc);
+        }
     }
     int lv_j = j;                          // layer voff / vneed currently describe
 
+    // SHORT (stationary units): a unit is NOT software-pipelined over the previous one.  Its top: what the previous unit owes (drain, publish), then
+    // its P row, then its dependencies, then its look-back row -- the P row and the unit's own rows (registers) need nothing from the neighbours, so
+    // GEMM1 runs the x[t] k-steps of pair 0 before it touches the look-back row (the "early half"; the packed K order is x[t] first for that).  The loads
+    // are issued and consumed in ONE iteration: across the back-edge the compiler's vmcnt bookkeeping is conservative, and a P row carried over
+    // as 64 accumulator registers costs GEMM1 fifty spilled ones.
+    constexpr bool early_half = SHORT;
     while (u >= 0 && !dead) {
         PT_MARK();
         // ---- TOP: P row requested; the rows of this unit were requested during the previous one ---------------------------
         int row, rc, nn, t;
         bool valid;
         unit_rows(u, lane, rows, p.N, p.T, p.T_magic, p.T_shift, row, valid, rc, nn, t);
+        if constexpr (SHORT) {
+            flush_owed();
+            PT_EV(3, j, u);
+            leave_layers(j);
+        }
         f32x16 acc[4];
         {
             int prow = 0;
@@ -601,16 +767,30 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
                 }
         }
+        if constexpr (SHORT) {
+            if (lv_j != j) { layer_vectors(j); lv_j = j; }
+            const unsigned bad = eval(dep_addr(j, u)) & ~1u;      // (its own rows are this wave's previous output: program order)
+            war_ok = (bad & kWarMask) == 0;
+            if (bad & kRawMask) {
+                wait_deps(j, u, kRawMask & ~1u, j, 4);
+                if (dead) break;
+            }
+            // the P row has had the wait to land: say so to the compiler's scoreboard (a builtin, not asm: the pass sees it), or it puts a vmcnt(0)
+            // -- the look-back row included -- in front of the first MFMA
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            load_xb(j, u, rxb);
+        }
         // the next task (claimed an iteration ago) and the bytes it depends on
         int j2 = j;
-        const int u2 = locate(__builtin_amdgcn_readfirstlane(claim_v), j2);
+        const int u2 = next_task(j, u, j2);
         unsigned bad2 = 0;                     // its dependency bits (one LDS byte per lane, read here under the P loads)
         if (u2 >= 0) {
             if (j2 != lv_j) { layer_vectors(j2); lv_j = j2; }
             bad2 = eval(dep_addr(j2, u2));
+            if (stat) bad2 &= ~1u;             // (its own rows are this very task's output: program order)
         }
 
-        if (p.x_first && j == 0) {
+        if (!SHORT && p.x_first && j == 0) {
             // rebuild this lane's 32 channels (8g + 4h + e) of h[t] and h[t-d] from the scalars; the operation order of
             // iaf_front_kernel / the FIRST variant of the per-layer kernel: round(x[t-1] w0), then fma(x[t], w1, .)
             const float x0 = rxc[0], x1v = rxc[1], xd0 = rxb[0], xd1 = rxb[1];
@@ -635,24 +815,43 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         // meanwhile); then the verdict on the next task's dependencies
         auto settle_top = [&]() {
             PT_PHASE(9);
+            if (!early_half) PT_EV(5, j, u);
             PT_BEGIN();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!early_half) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (early half: nothing is owed here -- the wait in front of this unit drained and published)
             PT_END(1);
-            publish();
-            if (left_upto < j) leave_layers(j);
-            if (u2 >= 0) claim_v = claim();
+            PT_EV(6, j, u);
+            if constexpr (!SHORT) {      // (SHORT: the top of the unit has done all of it)
+                publish();
+                if (left_upto < j) leave_layers(j);
+                if (u2 >= 0) claim_v = claim();
+            }
             PT_ADD(5, 1);
             PT_MARK();
         };
         // the next task's rows: requested between GEMM1 and GEMM2, in flight under GEMM2 + gating + stores -- if their
         // producers are done (normally they are a layer-sweep old); otherwise behind this unit's stores, after a wait
+        // (stationary units) the word of a LEFT NEIGHBOUR's unit the next task waits for: asked for here, under GEMM2 -- a poll is a
+        // 2 us round trip, and that unit, its workgroup's top one, is usually through by now; the answer goes into its byte before the wait
+        int early_v = -1;
         auto prefetch_next = [&]() {
             PT_PHASE(10);
-            if (u2 >= 0 && !(bad2 & kRawMask)) {
+            if (u2 >= 0 && !(bad2 & kRawMask) && !stat) {
                 load_x(j2, u2, rxb, rxc);
             } else {      // (ends the old rows' live ranges: without it they would occupy 64 registers through both GEMMs)
 #pragma unroll
                 for (int k = 0; k < 32; ++k) rxb[k] = rxc[k] = 0.f;
+            }
+            if (stat && u2 >= 0 && (bad2 & 0x36u)) {
+                // (lanes 1 / 2: the left neighbour's unit; lanes 32..: the RIGHT neighbours' workgroup words when the next task's stores will have
+                //  to know that the readers of their ring slot are through -- the top unit's WAR side, a 2 - 3 us poll in front of its stores otherwise)
+                const int a2 = dep_addr(j2, u2);
+                const int cnt_r = w + p.reach_wgs < p.last_wg ? p.reach_wgs : p.last_wg - w;
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                if ((lo == 1 || lo == 2) && a2 >= kLeftB && a2 < kDoneB)
+                    early_v = __hip_atomic_load(uprog_n + (size_t)(u_begin - kLeftN + a2 - kLeftB) * kUnitStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if ((bad2 & 0x30u) && lo >= 32 && lo - 32 < cnt_r)
+                    early_v = __hip_atomic_load(prog_n + (size_t)(w + 1 + lo - 32) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -664,6 +863,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             float xc[32], xb[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) { xc[k] = rxc[k]; xb[k] = rxb[k]; }
+            if constexpr (SHORT) {      // (SHORT: the look-back row arrives unselected, see load_xb; rows left of the utterance start are zero, modules.py:24-28)
+                if (!__all(t >= dil_of(j))) {
+                    const bool hp = t >= dil_of(j);
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) xb[k] = hp ? xb[k] : 0.f;
+                }
+            }
             settle_top();
             const float* Af = lds + (j & 1) * kSlot;                 // [kA1 | kA2 minus its last fragment]
             f32x4 a[4];
@@ -712,30 +918,48 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             const f16x8* A1 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot);
             const f16x8* A2 = reinterpret_cast<const f16x8*>(lds + (j & 1) * kSlot + kA1Size);
 
-            f16x8 bh[8], bl[8];      // B operands: k-steps 0..3 = x[t-d], 4..7 = x[t]
+            f16x8 bh[8], bl[8];      // B operands: bh[0..3] = x[t-d], bh[4..7] = x[t]; packed K order: x[t] first (pwv_layer_f16.hip)
             float xc[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) xc[k] = rxc[k];
-            split8<0>(rxb, bh[0], bl[0]);
-            split8<8>(rxb, bh[1], bl[1]);
-            split8<16>(rxb, bh[2], bl[2]);
-            split8<24>(rxb, bh[3], bl[3]);
+            split8<0>(xc, bh[4], bl[4]);
+            split8<8>(xc, bh[5], bl[5]);
+            split8<16>(xc, bh[6], bl[6]);
+            split8<24>(xc, bh[7], bl[7]);
             settle_top();
-            auto bxh = [&](int s) -> f16x8 { return bh[s]; };
-            auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+            auto bxh = [&](int s) -> f16x8 { return bh[s ^ 4]; };
+            auto bxl = [&](int s) -> f16x8 { return bl[s ^ 4]; };
             f16x8 oh[4], ol[4];
             f16x8 ah[4], al[4];
             f16x8 lf = {0, 0, 0, 0, 0, 0, 0, 0};
 
-            // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]); x[t] is split under its first four MFMA groups ------------
+            {
+            // ---- GEMM1, row-tile pair 0 = (F[0:32], G[0:32]); x[t-d] is split under its first four MFMA groups ----------
             first_frags<8, 2, 0, 2, 4>(A1, lane, ah, al);
             gemm16<8, 2, 0, 2, 4>(
                 A1, lane, acc, ah, al, bxh, bxl,
                 [&](int s) {
-                    if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
-                    if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
-                    if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
-                    if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+                    if constexpr (SHORT) {      // early half: the look-back row is waited for HERE, behind the x[t] k-steps of pair 0
+                        if (s == 3) {
+                            PT_EV(14, j, u);
+                            if (!__all(t >= dil_of(j))) {      // (rows left of the utterance start: zero, modules.py:24-28)
+                                const bool hp = t >= dil_of(j);
+#pragma unroll
+                                for (int k = 0; k < 32; ++k) rxb[k] = hp ? rxb[k] : 0.f;
+                            }
+                            split8<0>(rxb, bh[0], bl[0]);
+                            split8<8>(rxb, bh[1], bl[1]);
+                            split8<16>(rxb, bh[2], bl[2]);
+                            split8<24>(rxb, bh[3], bl[3]);
+                            asm volatile("" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]), "+v"(bh[3]), "+v"(bl[3]));
+                            PT_EV(5, j, u);
+                        }
+                    } else {
+                        if (s == 0) { split8<0>(rxb, bh[0], bl[0]); asm volatile("" : "+v"(bh[0]), "+v"(bl[0])); }
+                        if (s == 1) { split8<8>(rxb, bh[1], bl[1]); asm volatile("" : "+v"(bh[1]), "+v"(bl[1])); }
+                        if (s == 2) { split8<16>(rxb, bh[2], bl[2]); asm volatile("" : "+v"(bh[2]), "+v"(bl[2])); }
+                        if (s == 3) { split8<24>(rxb, bh[3], bl[3]); asm volatile("" : "+v"(bh[3]), "+v"(bl[3])); }
+                    }
                 },
                 [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
             // ---- pair 1 = (F[32:64], G[32:64]); pair 0 is gated + split under these MFMAs -----------------------------------
@@ -750,6 +974,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                     if (s == 5) lf = *reinterpret_cast<const f16x8*>(lastfrag);      // lands under the last two k-steps
                 },
                 [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<4, 2, 0, 1, 2>(A2, lane, nh, nl); });
+            }
 
             // ---- GEMM2: dense 64 -> 64, accumulator starts at x[t] + dense_bias ---------------------------------------------
 #pragma unroll
@@ -777,12 +1002,23 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         }
         if (dead) break;
         PT_PHASE(11);
+        PT_EV(1, j, u);
         // ---- stores (after the readers of the ring slot they overwrite are known to be done) -------------------------------
         if (!war_ok) {
-            PT_BEGIN();
-            wait_deps(j, u, kWarMask, lv_j, 5);
-            PT_END(3);
-            if (dead) break;
+            // (that verdict is a task old: look again before the machinery of a wait -- drain, leave, poll -- is set in motion; 1 us per unit on
+            //  short inputs, where every unit's verdict is stale, profiles/r06_short_timeline.md)
+            unsigned badw = kWarMask;
+            if constexpr (SHORT) {
+                if (lv_j != j) layer_vectors(j);
+                badw = eval(dep_addr(j, u)) & kWarMask;
+                if (lv_j != j) layer_vectors(lv_j);
+            }
+            if (badw) {
+                PT_BEGIN();
+                wait_deps(j, u, kWarMask, lv_j, 5);
+                PT_END(3);
+                if (dead) break;
+            }
         }
         {
             const int so = out_soff(j);
@@ -809,11 +1045,22 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        PT_EV(2, j, u);
 
         // ---- move on ------------------------------------------------------------------------------------------------------
         prev_addr = kDoneB + (u - u_begin);
         prev_j = j;
-        if (u2 >= 0 && (bad2 & kRawMask)) {
+        if (stat && u2 >= 0 && (bad2 & 0x36u)) {      // the early poll's answer (lv_j == j2 here)
+            const int a2 = dep_addr(j2, u2);
+            if (early_v >= 0 && lane < 32) lb[a2] = (unsigned char)(early_v > 255 ? 255 : early_v);
+            if ((bad2 & 0x30u) && w < p.last_wg && __ballot(lane >= 32 && early_v >= 0 && early_v < j2 - 1) == 0 && (int)lb[kSeenRB] < j2 - 1)
+                lb[kSeenRB] = (unsigned char)(j2 - 1);
+        }
+        if constexpr (SHORT) {
+            // (the next unit's top drains, publishes, waits and loads; its own rows are these accumulators)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) rxc[k] = acc2[k >> 4][k & 15];
+        } else if (u2 >= 0 && (bad2 & kRawMask)) {
             // the next task's producers were still at work when this unit looked: publish what this wave owes (a wave never
             // spins while holding unpublished work), wait, then load with the latency exposed
             PT_BEGIN();
@@ -825,12 +1072,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         }
         j = j2;
         u = u2;
-        war_ok = (bad2 & kWarMask) == 0;
+        if constexpr (!SHORT) war_ok = (bad2 & kWarMask) == 0;
         PT_PHASE(12);
     }
     // the last unit's stores, a refill this wave still owes, and the layers it has not yet counted itself out of
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!dead) {
+    if (!dead && !(loader_mode && wave >= n)) {      // (with a loader the idle waves are not counted: it waits for the n active ones)
         publish();
         leave_layers(L);
         if (dma_pending >= 0) flush_owed();
@@ -846,6 +1093,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     {
         if (p.tail_q > 0) {
             tail_done = true;
+            PT_EV(8, L, -1);
             __syncthreads();                       // every wave of the workgroup is out of the task loop (its stores drained, its layers left)
             const int wg_dead = __builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1]);
             __syncthreads();                       // ... and has read that word before the weights overwrite it
@@ -878,6 +1126,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                   // the head's weights are resident
+                PT_EV(9, L, -1);
                 const f16x8* A1 = reinterpret_cast<const f16x8*>(lds);
                 const f16x8* HS = reinterpret_cast<const f16x8*>(lds + kHS);
                 const f16x8* H1 = reinterpret_cast<const f16x8*>(lds + kH1);
@@ -991,12 +1240,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         float xc[32];
 #pragma unroll
                         for (int i = 0; i < 32; ++i) xc[i] = txc[i];
-                        split8<0>(txb, bh[0], bl[0]);
-                        split8<8>(txb, bh[1], bl[1]);
-                        split8<16>(txb, bh[2], bl[2]);
-                        split8<24>(txb, bh[3], bl[3]);
-                        auto bxh = [&](int s) -> f16x8 { return bh[s]; };
-                        auto bxl = [&](int s) -> f16x8 { return bl[s]; };
+                        split8<0>(xc, bh[4], bl[4]);
+                        split8<8>(xc, bh[5], bl[5]);
+                        split8<16>(xc, bh[6], bl[6]);
+                        split8<24>(xc, bh[7], bl[7]);
+                        auto bxh = [&](int s) -> f16x8 { return bh[s ^ 4]; };
+                        auto bxl = [&](int s) -> f16x8 { return bl[s ^ 4]; };
                         float o[32];
                         f16x8 oh[4], ol[4];
                         f16x8 ah[4], al[4];
@@ -1004,10 +1253,10 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         gemm16<8, 2, 0, 2, 4>(
                             A1, lane, acc, ah, al, bxh, bxl,
                             [&](int s) {
-                                if (s == 0) { split8<0>(xc, bh[4], bl[4]); asm volatile("" : "+v"(bh[4]), "+v"(bl[4])); }
-                                if (s == 1) { split8<8>(xc, bh[5], bl[5]); asm volatile("" : "+v"(bh[5]), "+v"(bl[5])); }
-                                if (s == 2) { split8<16>(xc, bh[6], bl[6]); asm volatile("" : "+v"(bh[6]), "+v"(bl[6])); }
-                                if (s == 3) { split8<24>(xc, bh[7], bl[7]); asm volatile("" : "+v"(bh[7]), "+v"(bl[7])); }
+                                if (s == 0) { split8<0>(txb, bh[0], bl[0]); asm volatile("" : "+v"(bh[0]), "+v"(bl[0])); }
+                                if (s == 1) { split8<8>(txb, bh[1], bl[1]); asm volatile("" : "+v"(bh[1]), "+v"(bl[1])); }
+                                if (s == 2) { split8<16>(txb, bh[2], bl[2]); asm volatile("" : "+v"(bh[2]), "+v"(bl[2])); }
+                                if (s == 3) { split8<24>(txb, bh[3], bl[3]); asm volatile("" : "+v"(bh[3]), "+v"(bl[3])); }
                             },
                             [&](f16x8(&nh)[4], f16x8(&nl)[4]) { first_frags<8, 2, 1, 2, 4>(A1, lane, nh, nl); });
                         gemm16<8, 2, 1, 2, 4>(
@@ -1090,6 +1339,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                         if (valid && h == 0) p.affine_out[row] = fmaf(p.affine_x[row], outv[0], outv[1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    PT_EV(10, L, unit);
                     unit = next;
                 }
             }
@@ -1116,11 +1366,13 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             // exit accounting (below) without the LDS counter: one thread, behind the barrier
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            PT_EV(11, L, -1);
             if (wave == 0) {
                 int done = 0;
                 if (lane == 0) done = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_readfirstlane(done) == p.active_wgs - 1) {
                     for (int k = lane; k < p.G * p.nwg; k += 64) __hip_atomic_store(p.prog + (size_t)k * kProgStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (SHORT) for (int k = lane; k < p.G * p.units; k += 64) __hip_atomic_store(p.uprog + (size_t)k * kUnitStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) {
                         __hip_atomic_store(p.abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1141,6 +1393,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             if (lane == 0) done = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__builtin_amdgcn_readfirstlane(done) == p.active_wgs - 1) {
                 for (int k = lane; k < p.G * p.nwg; k += 64) __hip_atomic_store(p.prog + (size_t)k * kProgStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (SHORT) for (int k = lane; k < p.G * p.units; k += 64) __hip_atomic_store(p.uprog + (size_t)k * kUnitStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) {
                     __hip_atomic_store(p.abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1184,7 +1437,7 @@ int pwv_persist_status(int** status) {
     return PWV_OK;
 }
 
-struct PersistPlan { int units, nwg, per_wg, last_wg, reach_wgs, xcd_map, tail_reach_wgs; };
+struct PersistPlan { int units, nwg, per_wg, last_wg, reach_wgs, xcd_map, tail_reach_wgs, unit_mode; };
 
 static int persist_plan(int G, long long rows, int n_layers, const int* dil, int cus, int max_wgs, int min_units, int tail_q, int tail_dil, PersistPlan& pl) {
     PWV_CHECK_ARG(G >= 1 && G <= PWV_MAX_NETS, "persistent stack: G=%d out of range", G);
@@ -1215,6 +1468,15 @@ static int persist_plan(int G, long long rows, int n_layers, const int* dil, int
     PWV_CHECK_ARG(pl.reach_wgs <= kMaxReachWgs, "persistent stack: dilation %d reaches over %d workgroups (max %d)", dmax, pl.reach_wgs, kMaxReachWgs);
     const int grid = G * pl.nwg;
     pl.xcd_map = (pl.nwg % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+    // Short inputs (a handful of units per workgroup and layer: every layer is ONE unit's latency per SIMD): progress per UNIT instead of per
+    // workgroup.  A range's bottom unit waits for the left neighbour's TOP units, which that workgroup computes FIRST; its workgroup word
+    // appears only when its slowest unit -- its own bottom one, which waited for ITS left neighbour -- is through: with workgroup words every
+    // layer of the chain costs a cross-workgroup hop (profiles/r06_short_timeline.md).  PWV_PERSIST_UNITWORDS=0 keeps the workgroup words (A/B).
+    static const int unit_words_env = [] { const char* e = getenv("PWV_PERSIST_UNITWORDS"); return e ? atoi(e) : 1; }();
+    static const int stationary_env = [] { const char* e = getenv("PWV_PERSIST_STATIONARY"); return e ? atoi(e) : 1; }();
+    static const int early_env = [] { const char* e = getenv("PWV_PERSIST_EARLYHALF"); return e ? atoi(e) : 1; }();
+    (void)stationary_env; (void)early_env;
+    pl.unit_mode = (unit_words_env && pl.per_wg <= kUnitModeMaxPerWg && reach <= kLeftN && pl.nwg > 1) ? 1 : 0;      // (the launcher: and a folded layer 0, if the run starts there)
     // the tail's layer looks back too (a stack whose LAST dilation is its largest passed the probe and failed at the launch)
     pl.tail_reach_wgs = 0;
     if (tail_q > 0) {
@@ -1249,7 +1511,8 @@ size_t pwv_persist_workspace_bytes(const pwv_persist_args* args) {
     const pwv_persist_args* a = &copy;
     if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, cus, a->max_workgroups, a->min_units_per_workgroup, a->tail_q, a->tail_dilation, pl) != PWV_OK) return 0;
     // progress words + the abort word + the exit counter (one 256-byte line) + one arrival counter per range (the tail's affine)
-    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256) + align256((size_t)pl.nwg * 4);
+    // (+ in unit mode one word per unit and net)
+    return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256) + align256((size_t)pl.nwg * 4) + (pl.unit_mode ? align256((size_t)a->G * pl.units * kUnitStride * 4) : 0);
 }
 
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream) {
@@ -1272,6 +1535,9 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t str
     p.abort = p.prog + (size_t)a->G * pl.nwg * kProgStride;
     p.exited = p.abort + 1;
     int* const pair_words = (int*)((char*)a->workspace + align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256));
+    p.uprog = (int*)((char*)pair_words + align256((size_t)pl.nwg * 4));
+    if (a->x_first && !a->first_fold[0]) pl.unit_mode = 0;      // (the short-input instantiation has no unfolded layer 0; same workspace either way)
+    p.unit_mode = pl.unit_mode;
     p.active_wgs = a->G * (pl.last_wg + 1);
     for (int g = 0; g < a->G; ++g) {
         PWV_CHECK_ARG(a->x_ring[g] && a->packed_layers[g] && a->proj[g], "pwv_wavenet_stack_persist_f32: NULL buffer for net %d", g);
@@ -1348,15 +1614,20 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t str
     p.trace = nullptr;
 #ifdef PWV_PTRACE
     { const char* e = getenv("PWV_PTRACE_PTR"); if (e) p.trace = (long long*)strtoull(e, nullptr, 0); }
+    p.trace_ev = nullptr;
+    { const char* e = getenv("PWV_PTRACE_EV_PTR"); if (e) p.trace_ev = (long long*)strtoull(e, nullptr, 0); }
 #endif
     hipStream_t s = (hipStream_t)stream;
     const size_t n16 = pwv_persist_workspace_bytes(a) / 16;      // (progress words, abort / exit line, pair counters)
     if (!a->workspace_clean)
         hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
-    if (a->precision == PWV_PREC_F32)
-        hipLaunchKernelGGL(stack_persist_kernel<true>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
-    else
-        hipLaunchKernelGGL(stack_persist_kernel<false>, dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+    if (a->precision == PWV_PREC_F32) {
+        if (pl.unit_mode) hipLaunchKernelGGL((stack_persist_kernel<true, true>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((stack_persist_kernel<true, false>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+    } else {
+        if (pl.unit_mode) hipLaunchKernelGGL((stack_persist_kernel<false, true>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((stack_persist_kernel<false, false>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "persistent stack kernel launch failed: %s", hipGetErrorString(e));
     return PWV_OK;
