@@ -274,6 +274,12 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
         return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, __builtin_amdgcn_readfirstlane((unsigned)span), 0x00020000);
     }();
+    const __amdgpu_buffer_rsrc_t proj_rs = [&]() {      // (SHORT: the P rows through a buffer descriptor)
+        const unsigned long long a = (unsigned long long)proj_n;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi2 << 32) | lo), 0, 0xFFFFFFFFu, 0x00020000);
+    }();
+    (void)proj_rs;
     const int slot_bytes = (int)(p.ring_stride * 4);
     auto in_soff = [&](int j) -> int { return ((j + 2 + p.rot) % 3) * slot_bytes; };
     auto out_soff = [&](int j) -> int { return ((j + p.rot) % 3) * slot_bytes; };
@@ -754,7 +760,21 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             leave_layers(j);
         }
         f32x16 acc[4];
-        {
+        if constexpr (SHORT) {
+            // (buffer loads, like the rows: the compiler's scoreboard takes "all but the last 8 loads have landed" for the P row only if both are the
+            //  same kind of vector-memory instruction; the launcher keeps the P rows of a short launch inside a descriptor's 4 GB)
+            int prow = 0;
+            if (p.cond_hop > 0) prow = nn * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
+            const int po = (prow * p.proj_row_stride + j * 128 + h * 64) * 4;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(proj_rs, po + (it * 16 + q * 4) * 4, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[it][q * 4 + e] = v[e];
+                }
+        } else {
             int prow = 0;
             if (p.cond_hop > 0) prow = nn * p.cond_frames + fast_div(t + p.cond_offset, p.hop_magic, p.hop_shift);
             const float* pr = proj_n + (size_t)prow * p.proj_row_stride + j * 128 + h * 64;
@@ -768,6 +788,14 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 }
         }
         if constexpr (SHORT) {
+            // (An "early half" -- GEMM1's x[t] k-steps of pair 0 run while the look-back row is still in flight -- needs the compiler's scoreboard to know that
+            //  the P row has landed when the look-back loads go out: a vmcnt(0) BUILTIN directly behind the P loads does that, inline asm or a wait further
+            //  down does not, and then the first MFMA gets a vmcnt(0), look-back row included.  Priced, profiles/r06_ab_experiments.md r06_u ... r06_x: with
+            //  that builtin the wait for the P row (0.7 us, this path's latency, not a miss: touching the rows from the loader wave two layers ahead changes
+            //  nothing) stands in front of the dependency check and costs more than the 24 MFMAs it frees: 0.457 against 0.452 ms at 1 x 16000; the P row
+            //  requested in FRONT of the drain delays the publication the neighbours wait for by 1 us: 0.462 ms.  So: P row and look-back row in one queue,
+            //  one wait in front of the first MFMA.)
+            PT_EV(15, j, u);
             if (lv_j != j) { layer_vectors(j); lv_j = j; }
             const unsigned bad = eval(dep_addr(j, u)) & ~1u;      // (its own rows are this wave's previous output: program order)
             war_ok = (bad & kWarMask) == 0;
@@ -775,10 +803,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 wait_deps(j, u, kRawMask & ~1u, j, 4);
                 if (dead) break;
             }
-            // the P row has had the wait to land: say so to the compiler's scoreboard (a builtin, not asm: the pass sees it), or it puts a vmcnt(0)
-            // -- the look-back row included -- in front of the first MFMA
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            PT_EV(16, j, u);
             load_xb(j, u, rxb);
+            PT_EV(18, j, u);
         }
         // the next task (claimed an iteration ago) and the bytes it depends on
         int j2 = j;
@@ -1537,6 +1564,10 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t str
     int* const pair_words = (int*)((char*)a->workspace + align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256));
     p.uprog = (int*)((char*)pair_words + align256((size_t)pl.nwg * 4));
     if (a->x_first && !a->first_fold[0]) pl.unit_mode = 0;      // (the short-input instantiation has no unfolded layer 0; same workspace either way)
+    {   // ... and reads the P rows through a buffer descriptor with 32-bit byte offsets
+        const long long p_rows = a->cond_hop > 0 ? (long long)a->N * a->cond_frames : 1;
+        if (p_rows * a->proj_row_stride * 4 >= (1ll << 31)) pl.unit_mode = 0;
+    }
     p.unit_mode = pl.unit_mode;
     p.active_wgs = a->G * (pl.last_wg + 1);
     for (int g = 0; g < a->G; ++g) {

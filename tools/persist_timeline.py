@@ -20,7 +20,7 @@ from pwv_amd.modules import WaveNet
 from pwv_amd.variables import VariableStore
 
 NAMES = {1: 'computed', 2: 'stores issued', 3: 'stores acked', 4: 'deps ok', 5: 'rows in', 6: 'top drained', 7: 'PROGRESS WORD', 8: 'tail entered',
-         9: 'head weights in', 10: 'tail unit done', 11: 'wg done', 12: 'WAR ok', 13: 'stores acked (WAR wait)'}
+         9: 'head weights in', 10: 'tail unit done', 11: 'wg done', 12: 'WAR ok', 13: 'stores acked (WAR wait)', 14: 'early half done', 15: 'P requested', 16: 'deps checked', 17: 'P landed', 18: 'look-back requested'}
 
 
 def main():

@@ -1,12 +1,9 @@
 #!/bin/bash
-# round-6 GPU call 28: SHORT instantiation (template), non-pipelined stationary units: persist tests, timeline, A/B vs HEAD on 16k / C1 / C3
+# round-6 GPU call 29: SHORT without the builtin wait (P row and look-back row in one queue): persist tests + A/B vs HEAD
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-O=gpurun_out/r06_x; mkdir -p $O
-( time timeout 1200 python -m pytest tests/test_gpu_persist.py -m gpu -q -x ) > $O/pytest_persist.log 2>&1; tail -3 $O/pytest_persist.log | head -1
-PWV_LIB=tools/libpwv_ptrace.so timeout 300 python tools/persist_timeline.py 16000 10 2 60 > $O/timeline_16000_10.txt 2>&1
-tail -22 $O/timeline_16000_10.txt | head -12
+O=gpurun_out/r06_y; mkdir -p $O
+( time timeout 1200 python -m pytest tests/test_gpu_persist.py -m gpu -q -x ) > $O/pytest_persist.log 2>&1; head -2 $O/pytest_persist.log | tail -1
 for k in 1 2 3; do for v in HEAD0 BASE; do lib=tools/abl_so/libpwv_$v.so; [ $v = BASE ] && lib=""; PWV_LIB=$lib python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-f32-exact --length 16000 2>/dev/null | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v 16k', round(d['ms_per_step'],4))"; done; done | tee $O/ab_16k.txt
 for k in 1 2 3; do for v in HEAD0 BASE; do lib=tools/abl_so/libpwv_$v.so; [ $v = BASE ] && lib=""; PWV_LIB=$lib python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-f32-exact --case bench/c1 2>/dev/null | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v c1', round(d['ms_per_step'],4), round(d['value']/1e6,1))"; done; done | tee $O/ab_c1.txt
-tools/ab.sh 3 HEAD0 BASE | tee $O/ab_c3.txt
