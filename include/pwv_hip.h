@@ -53,7 +53,7 @@ const char* pwv_last_error(void);
 /* PWV_HIP_VERSION of the library that was loaded: major * 100 + minor.  A change of the major number changes the layout of an
  * argument struct: 3xx = pwv_persist_args begins with `struct_size`.  A client compiled against this header checks
  * pwv_version() / 100 == PWV_HIP_VERSION / 100 once after loading the library. */
-#define PWV_HIP_VERSION 300
+#define PWV_HIP_VERSION 301
 int pwv_version(void);
 /* number of compute units of the current device (grid sizing); <0 on error */
 int pwv_device_cus(void);
@@ -471,6 +471,12 @@ typedef struct pwv_persist_args {
 } pwv_persist_args;
 
 size_t pwv_persist_workspace_bytes(const pwv_persist_args* args);
+/* 1 if pwv_wavenet_stack_persist_f32 takes its SHORT-INPUT instantiation for `args` (round 6; at most 7 units of 32 rows per workgroup and layer, i.e. up to
+ * about 28000 rows for two nets on 256 CUs: progress words per unit instead of per workgroup, a unit stays on one wave through all layers -- its own rows never
+ * leave the registers --, a loader wave refills the weights; same results bit for bit), 0 if the general one, -1 on arguments the launch would refuse.
+ * Reads what pwv_persist_workspace_bytes reads, and x_first, first_fold, cond_hop, cond_frames, proj_row_stride.  PWV_PERSIST_UNITWORDS=0 in the
+ * environment keeps every launch on the general instantiation (A/B). */
+int pwv_persist_short_input(const pwv_persist_args* args);
 int pwv_persist_status(int** status);
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream);
 

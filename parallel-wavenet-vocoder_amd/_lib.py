@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('PWV_LIB') or os.path.join(_PKG_DIR, 'libpwv_hip.so') 
 CSRC = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('pwv_layer.hip', 'pwv_layer_f16.hip', 'pwv_layer_h16.hip', 'pwv_misc.hip',
                                                     'pwv_stack_persist.hip', 'pwv_norm.hip', 'pwv_audio.hip')]
 
-HEADER_VERSION = 300          # PWV_HIP_VERSION of include/pwv_hip.h these ctypes mirrors were written against
+HEADER_VERSION = 301          # PWV_HIP_VERSION of include/pwv_hip.h these ctypes mirrors were written against
 FIRST_FOLD_FLOATS = 2048      # PWV_FIRST_FOLD_FLOATS
 PWV_MAX_NETS = 2
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     'pwv_head_packed_floats', 'pwv_pack_head_f32', 'pwv_wavenet_head_f32', 'pwv_wavenet_stack_f32',
     'pwv_iaf_front_f16', 'pwv_cond_to_f16', 'pwv_tile32_floats', 'pwv_rows_to_tile32_f32', 'pwv_tile32_to_rows_f32',
     'pwv_linear_split_f32', 'pwv_cond_project_f32', 'pwv_pack_first_fold_f16x3', 'pwv_pack_first_fold_f32', 'pwv_cond_split_f16', 'pwv_range_flag', 'pwv_status_words_alloc', 'pwv_status_words_free', 'pwv_range_check_f32', 'pwv_range_stats_f32',
-    'pwv_persist_workspace_bytes', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32',
+    'pwv_persist_workspace_bytes', 'pwv_persist_short_input', 'pwv_persist_status', 'pwv_wavenet_stack_persist_f32',
     'pwv_wav_to_mel_db_f32', 'pwv_pack_proj_f32', 'pwv_instance_norm_workspace_bytes', 'pwv_instance_norm_f32', 'pwv_channel_affine_f32', 'pwv_add_f32', 'pwv_gate_f32',
 )
 
@@ -268,6 +268,8 @@ def _declare(lib):
     lib.pwv_gate_f32.argtypes = [f32p, f32p, f32p, c_int64, c_void_p]
     lib.pwv_persist_workspace_bytes.restype = c_size_t
     lib.pwv_persist_workspace_bytes.argtypes = [POINTER(PersistArgs)]
+    lib.pwv_persist_short_input.restype = c_int
+    lib.pwv_persist_short_input.argtypes = [POINTER(PersistArgs)]
     lib.pwv_persist_status.argtypes = [POINTER(c_void_p)]
     lib.pwv_wavenet_stack_persist_f32.argtypes = [POINTER(PersistArgs), c_void_p]
     lib.pwv_range_stats_f32.argtypes = [f32p] * 8 + [c_int, f32p, c_void_p]

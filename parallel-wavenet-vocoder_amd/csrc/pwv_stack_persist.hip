@@ -56,7 +56,11 @@ constexpr int kLeftN = 32;                                 // unit mode (short i
 constexpr int kLeftB = (kCfF + 128) * 4;                   // ... in front of the own units' bytes, so one linear address serves both
 constexpr int kDoneB = kLeftB + kLeftN;                    // byte offset of the per-unit "layers completed" bytes
 constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 832 units per workgroup
-constexpr int kUnitModeMaxPerWg = 4;                       // unit mode up to this many units per workgroup and layer
+#ifndef PWV_SHORT_MAX_UNITS
+#define PWV_SHORT_MAX_UNITS 7      // (wave 7 is the loader.  Against the general kernel: 4 units per workgroup -17 %, 5: -8 %, 6: -11.5 %, 7: -11 %; profiles/r06_ab_experiments.md, r06_z2)
+#endif
+constexpr int kUnitModeMaxPerWg = PWV_SHORT_MAX_UNITS;
+static_assert(kUnitModeMaxPerWg <= 7, "the short-input instantiation keeps wave 7 as its loader");                       // unit mode up to this many units per workgroup and layer
 constexpr int kUnitStride = 32;                            // ints between two units' words (own 128-byte lines: a poll asks for exactly the unit it waits for)
 constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
 constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     if (n <= 0) return;      // owns nothing; nobody waits for it (the neighbour sets stop at the last owning workgroup)
     const int L = p.n_layers;
     constexpr bool stat = SHORT;                        // stationary units (below, at the task loop): n <= kUnitModeMaxPerWg <= 8 units, one per wave
-    constexpr bool loader_mode = SHORT;                 // ... leave idle waves (n <= kUnitModeMaxPerWg = 4 < 8): wave 7 is the workgroup's loader
+    constexpr bool loader_mode = SHORT;                 // ... leave wave 7 idle (n <= kUnitModeMaxPerWg = 7): it is the workgroup's loader
 #ifdef PWV_PTRACE
     int pt_nev = 0;
 #endif
@@ -1517,6 +1521,16 @@ static int persist_plan(int G, long long rows, int n_layers, const int* dil, int
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// the short-input instantiation: the plan's verdict (units per workgroup, look-back reach), and a folded layer 0 if the run starts with one (it has
+// no unfolded form), and the P rows inside the 2 GB its buffer descriptor's 32-bit offsets reach.  (The workspace is sized by the plan alone.)
+static int short_input_mode(const pwv_persist_args* a, const PersistPlan& pl) {
+    if (!pl.unit_mode) return 0;
+    if (a->x_first && !a->first_fold[0]) return 0;
+    const long long p_rows = a->cond_hop > 0 ? (long long)a->N * a->cond_frames : 1;
+    if (p_rows * a->proj_row_stride * 4 >= (1ll << 31)) return 0;
+    return 1;
+}
+
 // The caller's struct, as far as the caller knows it (struct_size), in front of zeros: a client compiled against an earlier minor version
 // of the header passes a shorter struct, and what lies behind it in its memory is not ours to read (a garbage `status`
 // pointer would be written through on a give-up, a garbage tail_q would switch the tail on)
@@ -1542,6 +1556,15 @@ size_t pwv_persist_workspace_bytes(const pwv_persist_args* args) {
     return align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256) + align256((size_t)pl.nwg * 4) + (pl.unit_mode ? align256((size_t)a->G * pl.units * kUnitStride * 4) : 0);
 }
 
+int pwv_persist_short_input(const pwv_persist_args* args) {
+    PersistPlan pl;
+    pwv_persist_args copy;
+    if (persist_args_copy(args, copy, "pwv_persist_short_input") != PWV_OK) return -1;
+    const pwv_persist_args* a = &copy;
+    if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, device_cus(), a->max_workgroups, a->min_units_per_workgroup, a->tail_q, a->tail_dilation, pl) != PWV_OK) return -1;
+    return short_input_mode(a, pl);
+}
+
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream) {
     pwv_persist_args copy;
     if (int rc0 = persist_args_copy(args, copy, "pwv_wavenet_stack_persist_f32")) return rc0;
@@ -1563,11 +1586,7 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t str
     p.exited = p.abort + 1;
     int* const pair_words = (int*)((char*)a->workspace + align256((size_t)a->G * pl.nwg * kProgStride * 4 + 256));
     p.uprog = (int*)((char*)pair_words + align256((size_t)pl.nwg * 4));
-    if (a->x_first && !a->first_fold[0]) pl.unit_mode = 0;      // (the short-input instantiation has no unfolded layer 0; same workspace either way)
-    {   // ... and reads the P rows through a buffer descriptor with 32-bit byte offsets
-        const long long p_rows = a->cond_hop > 0 ? (long long)a->N * a->cond_frames : 1;
-        if (p_rows * a->proj_row_stride * 4 >= (1ll << 31)) pl.unit_mode = 0;
-    }
+    pl.unit_mode = short_input_mode(a, pl);
     p.unit_mode = pl.unit_mode;
     p.active_wgs = a->G * (pl.last_wg + 1);
     for (int g = 0; g < a->G; ++g) {

@@ -790,7 +790,8 @@ def _run_stack_persist(lib, nets, plans, projs, bufs, outs, x_first, x_limit, ro
         check(lib.pwv_wavenet_stack_persist_f32(ctypes.byref(pa), s), 'pwv_wavenet_stack_persist_f32')
         if ev is not None:
             ev[1].record()
-            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt, 1 if j0 == 0 else 0, 1 if (tail and last_run) else 0))
+            EVENT_LOG.append(('persist', ev[0], ev[1], G, cnt, 1 if j0 == 0 else 0, 1 if (tail and last_run) else 0,
+                              int(lib.pwv_persist_short_input(ctypes.byref(pa)))))      # [7]: the short-input instantiation (round 6)
         out_slot = (cnt - 1 + rot) % 3      # where this run left its last layer
         rot = (out_slot + 1) % 3            # the next run's input buffer is (2 + rot') % 3 == out_slot
     if tail:

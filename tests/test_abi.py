@@ -28,7 +28,7 @@ def test_header_symbols_exported(built_lib):
 def test_packed_sizes_and_column_map(built_lib):
     from pwv_amd import _lib
     lib = built_lib
-    assert lib.pwv_version() == _lib.HEADER_VERSION == 300      # PWV_HIP_VERSION: 3xx = pwv_persist_args begins with struct_size
+    assert lib.pwv_version() == _lib.HEADER_VERSION == 301      # PWV_HIP_VERSION: 3xx = pwv_persist_args begins with struct_size
     base = lib.pwv_layer_packed_floats(0, 0)
     assert base == 4 * 16 * 64 * 4 + 2 * 8 * 64 * 4 + 64               # filter|gate + dense + dense bias
     assert lib.pwv_layer_packed_floats(1, 0) == base + 8192 + 128     # + skip + skip bias

@@ -48,7 +48,10 @@ def persist_knobs():
     (2, 24000, 30, 2, 2, 32),       # two units per workgroup over 30 layers, two utterances
     (1, 160000, 30, 2, 0, 10),      # 28 residual layers as three runs (10 + 9 + 9) that hand the ring on
     (1, 48000, 13, 1, 0, 4),        # 11 residual layers as runs of 4 + 4 + 3: every ring rotation
-    (1, 96, 5, 2, 0, 32)])          # three units in all
+    (1, 96, 5, 2, 0, 32),           # three units in all
+    # round 6, the short-input instantiation (per-unit progress words, stationary units, a loader wave): 5 and 7 units per workgroup, its upper end
+    # (8 units per workgroup: the general kernel again), utterance starts inside units, one net on all CUs
+    (1, 20000, 10, 2, 0, 32), (1, 28000, 12, 2, 0, 32), (1, 32000, 10, 2, 0, 32), (2, 14001, 10, 2, 0, 32), (3, 10000, 15, 1, 0, 32)])
 def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_knobs, n, t, L, G, min_units, max_layers, precision):
     import torch
     engine = persist_knobs
@@ -77,6 +80,13 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(gpu, persist_kn
         engine.EVENT_LOG = None
     runs = engine._persist_runs(L, 0)       # (scalar-input nets: the launch starts with the net's layer 0)
     assert [e[0] for e in log] == ['persist'] * (3 * len(runs)) and sum(e[4] for e in log) == 3 * (L - 1)      # it really was persistent
+    # ... and which instantiation it was: at most 7 units of 32 rows per workgroup and layer is the short-input one (256 CUs assumed)
+    from pwv_amd import _lib
+    cus = _lib.lib().pwv_device_cus()
+    if cus == 256 and (n, t, G, min_units) in ((1, 16000, 2, 0), (1, 20000, 2, 0), (1, 28000, 2, 0), (2, 14001, 2, 0), (3, 10000, 1, 0), (1, 16000, 2, 1)):
+        assert all(e[7] == 1 for e in log)
+    if cus == 256 and (n, t, G) in ((1, 160000, 2), (1, 32000, 2), (1, 65536, 2)):
+        assert all(e[7] == 0 for e in log)
 
 
 @pytest.mark.parametrize('n,t,L,G,Q,min_units,max_layers', [

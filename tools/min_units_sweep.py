@@ -27,7 +27,7 @@ def main():
     model = IAFVocoder(batch_size=1, length=a.length, store=store)
     model(None, mel, is_training=False)
     for rounds in range(2):
-        for mu in (2, 3, 4, 5, 6, 8):
+        for mu in (1, 2, 3, 4, 5, 6, 8):
             engine.PERSIST_MIN_UNITS = mu
             g = GraphedVocoder(model)
             for _ in range(5):
