@@ -60,7 +60,13 @@ constexpr int kMaxUnitsWg = kLdsFloats * 4 - kDoneB;       // 832 units per work
 #define PWV_SHORT_MAX_UNITS 7      // (wave 7 is the loader.  Against the general kernel: 4 units per workgroup -17 %, 5: -8 %, 6: -11.5 %, 7: -11 %; profiles/r06_ab_experiments.md, r06_z2)
 #endif
 constexpr int kUnitModeMaxPerWg = PWV_SHORT_MAX_UNITS;
-static_assert(kUnitModeMaxPerWg <= 7, "the short-input instantiation keeps wave 7 as its loader");                       // unit mode up to this many units per workgroup and layer
+static_assert(kUnitModeMaxPerWg <= 7, "the short-input instantiation keeps wave 7 as its loader");
+#ifndef PWV_MEDIUM_MAX_UNITS
+#define PWV_MEDIUM_MAX_UNITS 0
+#endif
+constexpr int kMediumMaxPerWg = PWV_MEDIUM_MAX_UNITS;
+constexpr int kMediumMode = (PWV_MEDIUM_MAX_UNITS) > 0 ? 1 : 0;      // (0: no such instantiation is built)
+                      // unit mode up to this many units per workgroup and layer
 constexpr int kUnitStride = 32;                            // ints between two units' words (own 128-byte lines: a poll asks for exactly the unit it waits for)
 constexpr int kFlagB = (kCtlF + 2) * 4;        // flag bytes: +0 seenL, +1 seenR, +2 / +3 newest layer in LDS slot 0 / 1, +4 always 255
 constexpr int kSeenLB = kFlagB, kSeenRB = kFlagB + 1, kWreadyB = kFlagB + 2, kTrueB = kFlagB + 4;
@@ -195,8 +201,11 @@ __device__ __forceinline__ void gemm_groups_dense(FR&& fr, f32x16 (&acc)[2], f32
 // SHORT (round 6): the instantiation for short inputs (at most kUnitModeMaxPerWg units per workgroup and layer: progress words per unit, stationary
 // units, a loader wave) -- a template parameter, not a run-time mode: as run-time branches in the general task loop the additions cost the long-input
 // launch 2.7 % of its step (SGPR spills reloaded per unit, profiles/r06_ab_experiments.md r06_r)
-template <bool F32, bool SHORT>
+// MODE 1 (medium inputs, 8 ... PWV_MEDIUM_MAX_UNITS units per workgroup): the general kernel with the progress words per unit only.
+template <bool F32, int MODE>
 __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams p) {
+    constexpr bool SHORT = MODE == 2;      // stationary units, loader wave, ... (everything below that says SHORT)
+    constexpr bool UNITW = MODE >= 1;      // progress words per unit
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     auto dep_addr = [&](int j, int u) -> int {
         const int v = u + (int)(short)vpack;
         int a = kDoneB - u_begin + v;
-        a = (v < u_begin && !SHORT) ? kSeenLB : a;      // (unit mode: the byte of that very unit, kLeftN bytes in front of the own ones)
+        a = (v < u_begin && !UNITW) ? kSeenLB : a;      // (unit mode: the byte of that very unit, kLeftN bytes in front of the own ones)
         a = v >= u_end ? kSeenRB : a;
         a = (v < 0 || v >= p.units) ? kTrueB : a;
         a = lane == 3 ? kWreadyB + (j & 1) : a;
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         int lo = lane;
         asm volatile("" : "+v"(lo));      // (address made here, not hoisted out of the task loop into a spilled register pair)
         if (lo < cnt) v = __hip_atomic_load(prog_n + (size_t)(w0 + lo) * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if constexpr (SHORT) {
+        if constexpr (UNITW) {
             const int m = wave_min(v);
             if (m >= need) lb[side ? kSeenRB : kSeenLB] = (unsigned char)m;
         } else {
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     auto publish = [&]() {               // (all lanes store the same byte: no exec juggling)
         if (prev_addr >= 0) {
             lb[prev_addr] = (unsigned char)(prev_j + 1);
-            if (SHORT && lane == 0) __hip_atomic_store(uprog_n + (size_t)(prev_addr - kDoneB + u_begin) * kUnitStride, prev_j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (UNITW && lane == 0) __hip_atomic_store(uprog_n + (size_t)(prev_addr - kDoneB + u_begin) * kUnitStride, prev_j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             prev_addr = -1;
         }
         if (dma_pending >= 0) { lb[kWreadyB + (dma_pending & 1)] = (unsigned char)dma_pending; dma_pending = -1; }
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             if (__builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) volatile int*)&ctl[1])) break;
             if ((k & 63) == 63 && (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
                                    __builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks)) break;
-            if constexpr (SHORT) {
+            if constexpr (UNITW) {
                 if ((bad & 0x6u) && __ballot((lane == 1 || lane == 2) && addr < kDoneB && addr >= kLeftB)) poll_units(addr, j);
             } else if ((bad & 0x6u) && __ballot(addr == kSeenLB && (lane == 1 || lane == 2))) poll_side(0, j);
             if ((bad & 0x30u) && __ballot(addr == kSeenRB && (lane == 4 || lane == 5))) poll_side(1, j - 1);
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             // (that verdict is a task old: look again before the machinery of a wait -- drain, leave, poll -- is set in motion; 1 us per unit on
             //  short inputs, where every unit's verdict is stale, profiles/r06_short_timeline.md)
             unsigned badw = kWarMask;
-            if constexpr (SHORT) {
+            if constexpr (UNITW) {
                 if (lv_j != j) layer_vectors(j);
                 badw = eval(dep_addr(j, u)) & kWarMask;
                 if (lv_j != j) layer_vectors(lv_j);
@@ -1403,7 +1412,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
                 if (lane == 0) done = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_readfirstlane(done) == p.active_wgs - 1) {
                     for (int k = lane; k < p.G * p.nwg; k += 64) __hip_atomic_store(p.prog + (size_t)k * kProgStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (SHORT) for (int k = lane; k < p.G * p.units; k += 64) __hip_atomic_store(p.uprog + (size_t)k * kUnitStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (UNITW) for (int k = lane; k < p.G * p.units; k += 64) __hip_atomic_store(p.uprog + (size_t)k * kUnitStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) {
                         __hip_atomic_store(p.abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1424,7 +1433,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             if (lane == 0) done = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__builtin_amdgcn_readfirstlane(done) == p.active_wgs - 1) {
                 for (int k = lane; k < p.G * p.nwg; k += 64) __hip_atomic_store(p.prog + (size_t)k * kProgStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (SHORT) for (int k = lane; k < p.G * p.units; k += 64) __hip_atomic_store(p.uprog + (size_t)k * kUnitStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (UNITW) for (int k = lane; k < p.G * p.units; k += 64) __hip_atomic_store(p.uprog + (size_t)k * kUnitStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) {
                     __hip_atomic_store(p.abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1507,7 +1516,11 @@ static int persist_plan(int G, long long rows, int n_layers, const int* dil, int
     static const int stationary_env = [] { const char* e = getenv("PWV_PERSIST_STATIONARY"); return e ? atoi(e) : 1; }();
     static const int early_env = [] { const char* e = getenv("PWV_PERSIST_EARLYHALF"); return e ? atoi(e) : 1; }();
     (void)stationary_env; (void)early_env;
-    pl.unit_mode = (unit_words_env && pl.per_wg <= kUnitModeMaxPerWg && reach <= kLeftN && pl.nwg > 1) ? 1 : 0;      // (the launcher: and a folded layer 0, if the run starts there)
+    pl.unit_mode = 0;      // 2: the short-input instantiation, 1: the general kernel with unit words (medium inputs)
+    if (unit_words_env && reach <= kLeftN && pl.nwg > 1) {
+        if (pl.per_wg <= kUnitModeMaxPerWg) pl.unit_mode = 2;      // (the launcher: and a folded layer 0, if the run starts there)
+        else if (pl.per_wg <= kMediumMaxPerWg) pl.unit_mode = 1;
+    }
     // the tail's layer looks back too (a stack whose LAST dilation is its largest passed the probe and failed at the launch)
     pl.tail_reach_wgs = 0;
     if (tail_q > 0) {
@@ -1524,11 +1537,12 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // the short-input instantiation: the plan's verdict (units per workgroup, look-back reach), and a folded layer 0 if the run starts with one (it has
 // no unfolded form), and the P rows inside the 2 GB its buffer descriptor's 32-bit offsets reach.  (The workspace is sized by the plan alone.)
 static int short_input_mode(const pwv_persist_args* a, const PersistPlan& pl) {
-    if (!pl.unit_mode) return 0;
-    if (a->x_first && !a->first_fold[0]) return 0;
+    if (pl.unit_mode != 2) return pl.unit_mode;
+    const int fallback = kMediumMaxPerWg > 0 ? 1 : 0;
+    if (a->x_first && !a->first_fold[0]) return fallback;
     const long long p_rows = a->cond_hop > 0 ? (long long)a->N * a->cond_frames : 1;
-    if (p_rows * a->proj_row_stride * 4 >= (1ll << 31)) return 0;
-    return 1;
+    if (p_rows * a->proj_row_stride * 4 >= (1ll << 31)) return fallback;
+    return 2;
 }
 
 // The caller's struct, as far as the caller knows it (struct_size), in front of zeros: a client compiled against an earlier minor version
@@ -1562,7 +1576,7 @@ int pwv_persist_short_input(const pwv_persist_args* args) {
     if (persist_args_copy(args, copy, "pwv_persist_short_input") != PWV_OK) return -1;
     const pwv_persist_args* a = &copy;
     if (persist_plan(a->G, (long long)a->N * a->T, a->n_layers, a->dilations, device_cus(), a->max_workgroups, a->min_units_per_workgroup, a->tail_q, a->tail_dilation, pl) != PWV_OK) return -1;
-    return short_input_mode(a, pl);
+    return short_input_mode(a, pl) == 2 ? 1 : 0;
 }
 
 int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t stream) {
@@ -1671,12 +1685,15 @@ int pwv_wavenet_stack_persist_f32(const pwv_persist_args* args, pwv_stream_t str
     const size_t n16 = pwv_persist_workspace_bytes(a) / 16;      // (progress words, abort / exit line, pair counters)
     if (!a->workspace_clean)
         hipLaunchKernelGGL(persist_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (int4*)a->workspace, n16);
+    const dim3 grid(a->G * pl.nwg), block(512);
     if (a->precision == PWV_PREC_F32) {
-        if (pl.unit_mode) hipLaunchKernelGGL((stack_persist_kernel<true, true>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((stack_persist_kernel<true, false>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+        if (pl.unit_mode == 2) hipLaunchKernelGGL((stack_persist_kernel<true, 2>), grid, block, 0, s, p);
+        else if (pl.unit_mode == 1 && kMediumMaxPerWg > 0) hipLaunchKernelGGL((stack_persist_kernel<true, kMediumMode>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((stack_persist_kernel<true, 0>), grid, block, 0, s, p);
     } else {
-        if (pl.unit_mode) hipLaunchKernelGGL((stack_persist_kernel<false, true>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((stack_persist_kernel<false, false>), dim3(a->G * pl.nwg), dim3(512), 0, s, p);
+        if (pl.unit_mode == 2) hipLaunchKernelGGL((stack_persist_kernel<false, 2>), grid, block, 0, s, p);
+        else if (pl.unit_mode == 1 && kMediumMaxPerWg > 0) hipLaunchKernelGGL((stack_persist_kernel<false, kMediumMode>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((stack_persist_kernel<false, 0>), grid, block, 0, s, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PWV_EHIP, "persistent stack kernel launch failed: %s", hipGetErrorString(e));
