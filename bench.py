@@ -23,6 +23,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                    (pwv_stack_args.ev_begin / ev_end, production launch path) against 8 TB/s; `traffic` = HBM bytes per
                    launch from the committed PMC passes (profiles/); the matrix-pipe view is beside it as roofline_mfma
                    (with --precision f32 the roles swap: fp32 MFMA roofline, HBM view beside it)
+  short_input   -- (N=1, default workload) the same model on ONE utterance of 16000 samples under graph replay: the latency-bound end of the
+                   path, where the persistent launch takes its short-input instantiation; reported beside `value`, never part of it
   cpu_baseline  -- the oracle's torch-CPU fp32 port of the same model timed on this host's cores on a bounded sample
                    (rank 0, N=1 only), cache-blocked in time and swept over {1, 2, 4, 8, 16, 32, physical cores} workers:
                    `value_1thread`, `value_best` (= `value`), `threads_swept`; a reported baseline, not the target.
@@ -822,6 +824,33 @@ def main():
                                                  'would be rerun in exact fp32 (f32_exact is that path)'}
             except Exception as e:
                 sys.stderr.write('range report failed (%s: %s)\n' % (type(e).__name__, e))
+        if n_gpus == 1 and not control and not dryrun and args.precision == 'f16x3' and not args.no_f32_exact and length > 16000 and not args.length:
+            # the SAME model on one SHORT utterance (16000 samples: the latency-bound end of the path, where the persistent launch takes its
+            # short-input instantiation -- csrc/pwv_stack_persist.hip, DESIGN.md section 4 "Short inputs"), untimed by the contract, reported beside it
+            try:
+                ls = 16000
+                mel_s = (torch.rand((1, 1 + ls // hop, n_mels), generator=torch.Generator().manual_seed(11)) * 2 - 1).to(dev)
+                from pwv_amd.graph import GraphedVocoder
+                ms_model = IAFVocoder(batch_size=1, length=ls, store=store, precision='f16x3')
+                ms_model.noise_seed = 3
+                ms_model(None, mel_s, is_training=False, verify=False)
+                gs = GraphedVocoder(ms_model)
+                gs.mel.copy_(mel_s)
+                for _ in range(5):
+                    gs(gs.mel)
+                torch.cuda.synchronize()
+                t0s = time.perf_counter()
+                for _ in range(50):
+                    os_ = gs(gs.mel)
+                torch.cuda.synchronize()
+                es = (time.perf_counter() - t0s) / 50
+                ms_model.verify()
+                assert torch.isfinite(os_).all()
+                result['short_input'] = {'workload': 'the same model, 1 utterance x %d samples, HIP graph replay (not part of `value`)' % ls,
+                                         'ms_per_step': es * 1e3, 'samples_per_s': ls / es, 'steps': 50,
+                                         'hbm_frac_of_8TBs': mb * ls / es / 1e9 / PEAK_HBM_GBS}
+            except Exception as e:
+                sys.stderr.write('short-input leg failed (%s: %s)\n' % (type(e).__name__, e))
         if n_gpus == 1 and not args.no_cpu_baseline and not control:
             from oracle.iaf_oracle import ModelConfig          # the oracle is only ever the CPU leg, never the timed path
             result['cpu_baseline'] = cpu_baseline(args.case, ModelConfig.from_hparam(hp), args.cpu_seconds)
