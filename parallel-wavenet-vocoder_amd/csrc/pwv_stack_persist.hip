@@ -756,11 +756,10 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
     int lv_j = j;                          // layer voff / vneed currently describe
 
     // SHORT (stationary units): a unit is NOT software-pipelined over the previous one.  Its top: what the previous unit owes (drain, publish), then
-    // its P row, then its dependencies, then its look-back row -- the P row and the unit's own rows (registers) need nothing from the neighbours, so
-    // GEMM1 runs the x[t] k-steps of pair 0 before it touches the look-back row (the "early half"; the packed K order is x[t] first for that).  The loads
-    // are issued and consumed in ONE iteration: across the back-edge the compiler's vmcnt bookkeeping is conservative, and a P row carried over
-    // as 64 accumulator registers costs GEMM1 fifty spilled ones.
-    constexpr bool early_half = SHORT;
+    // its P row, then its dependencies, then its look-back row.  The loads are issued and consumed in ONE iteration: across the back-edge the
+    // compiler's vmcnt bookkeeping is conservative, and a P row carried over as 64 accumulator registers costs GEMM1 fifty spilled ones.  (The packed
+    // K order is x[t] first so that GEMM1 could start on the unit's own rows while the look-back row is in flight -- the "early half" -- which the
+    // measurements of round 6 did not reward in any form the compiler or inline asm allows; see the comment at the dependency check below.)
     while (u >= 0 && !dead) {
         PT_MARK();
         // ---- TOP: P row requested; the rows of this unit were requested during the previous one ---------------------------
@@ -855,9 +854,9 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
         // meanwhile); then the verdict on the next task's dependencies
         auto settle_top = [&]() {
             PT_PHASE(9);
-            if (!early_half) PT_EV(5, j, u);
+            if (!SHORT) PT_EV(5, j, u);
             PT_BEGIN();
-            if (!early_half) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (early half: nothing is owed here -- the wait in front of this unit drained and published)
+            if (!SHORT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (SHORT: nothing is owed here -- the top of this unit has drained and published)
             PT_END(1);
             PT_EV(6, j, u);
             if constexpr (!SHORT) {      // (SHORT: the top of the unit has done all of it)
@@ -979,7 +978,7 @@ __global__ __launch_bounds__(512) void stack_persist_kernel(const PersistParams 
             gemm16<8, 2, 0, 2, 4>(
                 A1, lane, acc, ah, al, bxh, bxl,
                 [&](int s) {
-                    if constexpr (SHORT) {      // early half: the look-back row is waited for HERE, behind the x[t] k-steps of pair 0
+                    if constexpr (SHORT) {      // the look-back row (no select behind its loads, see load_xb) is zeroed left of the utterance start and split HERE, in one piece
                         if (s == 3) {
                             PT_EV(14, j, u);
                             if (!__all(t >= dil_of(j))) {      // (rows left of the utterance start: zero, modules.py:24-28)
@@ -1513,9 +1512,6 @@ static int persist_plan(int G, long long rows, int n_layers, const int* dil, int
     // appears only when its slowest unit -- its own bottom one, which waited for ITS left neighbour -- is through: with workgroup words every
     // layer of the chain costs a cross-workgroup hop (profiles/r06_short_timeline.md).  PWV_PERSIST_UNITWORDS=0 keeps the workgroup words (A/B).
     static const int unit_words_env = [] { const char* e = getenv("PWV_PERSIST_UNITWORDS"); return e ? atoi(e) : 1; }();
-    static const int stationary_env = [] { const char* e = getenv("PWV_PERSIST_STATIONARY"); return e ? atoi(e) : 1; }();
-    static const int early_env = [] { const char* e = getenv("PWV_PERSIST_EARLYHALF"); return e ? atoi(e) : 1; }();
-    (void)stationary_env; (void)early_env;
     pl.unit_mode = 0;      // 2: the short-input instantiation, 1: the general kernel with unit words (medium inputs)
     if (unit_words_env && reach <= kLeftN && pl.nwg > 1) {
         if (pl.per_wg <= kUnitModeMaxPerWg) pl.unit_mode = 2;      // (the launcher: and a folded layer 0, if the run starts there)

@@ -326,3 +326,18 @@ def test_a_tail_that_reaches_too_far_runs_as_its_own_launch(gpu, persist_knobs):
     assert engine.persist_status() == 0 and [e[0] for e in log] == ['persist'] and log[0][6] == 0      # persistent layers, no tail in the launch
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_random_shapes_through_the_persistent_launch_under_load(gpu):
+    """Round 6: the protocol's stress test (tools/persist_fuzz.py) -- 80 random (utterances, length, layers, nets, units per workgroup, layers per run,
+    arithmetic) through the persistent launch, four times each on one workspace, against the per-layer launches bit for bit, with a second stream of
+    unrelated memory traffic beside it (hand-off bugs hide on an idle chip): lengths that are no multiple of 32, utterance starts inside units, one to
+    seven units per workgroup (the short-input instantiation: per-unit progress words, stationary units, the loader wave) and beyond (the general one)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'persist_fuzz.py'), '--cases', '80', '--seed', '5', '--load'],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert ' 0 failed' in r.stdout
