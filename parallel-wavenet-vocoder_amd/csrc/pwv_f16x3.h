@@ -15,7 +15,14 @@ __device__ __forceinline__ void split8(const float (&x)[N], f16x8& hi, f16x8& lo
     for (int q = 0; q < 8; q += 2) {
         const f32x2 v = {x[OFF + q], x[OFF + q + 1]};
         const f16x2 h = __builtin_convertvector(v, f16x2);
-        const f32x2 r = v - __builtin_convertvector(h, f32x2);
+        // x - float(hi) with the fp16 halves read in place (round 6: v_fma_mix_f32, two instructions instead of two conversions and a packed subtract -- the
+        // compiler folds fma(float(h), -1, x) back into the subtract, hence asm; same value: the difference is exact either way.  -60 VALU per 32-row unit:
+        // C3 -0.9 %, C5 -0.9 %, 1 x 16000 -1.1 %, profiles/r06_ab_experiments.md r06_z17)
+        // (The hi conversion above stays the compiler's: it is the FIRST reader of x, which may be an MFMA result, and the hazard recogniser does not see into
+        //  asm.  The lo conversion stays the compiler's too: as asm it gave the gain back -- C3 -0.13 % instead of -0.86 %, r06_z19.)
+        f32x2 r;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(h), "v"(v[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(h), "v"(v[1]));
         const f16x2 l = __builtin_convertvector(r, f16x2);
         hi[q] = h[0];
         hi[q + 1] = h[1];
